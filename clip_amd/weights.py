@@ -1,0 +1,68 @@
+"""Procedural (counter-based) weights for offline parity and benchmarking.
+
+No pretrained checkpoint is reachable offline, so parity vectors and bench runs use weights
+drawn from a generator DEFINED HERE: numpy Philox keyed by (seed, crc32(tensor name)).  The same
+state dict is loaded into the reference model (oracle/gen_golden.py) and into the HIP engine, so
+only seeds + inputs + outputs need to be committed as fixtures.
+
+Key layout is the reference's: 201 keys for the context model
+(/root/reference/sentclf/bert_model.py:13-21 + transformers BertModel), see state_dict_keys().
+"""
+import zlib
+
+import numpy as np
+import torch
+
+from .config import BertConfig
+
+
+def state_dict_shapes(cfg: BertConfig):
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    s = {
+        "bert.embeddings.word_embeddings.weight": (cfg.vocab_size, H),
+        "bert.embeddings.position_embeddings.weight": (cfg.max_position_embeddings, H),
+        "bert.embeddings.token_type_embeddings.weight": (cfg.type_vocab_size, H),
+        "bert.embeddings.LayerNorm.weight": (H,),
+        "bert.embeddings.LayerNorm.bias": (H,),
+    }
+    for i in range(cfg.num_hidden_layers):
+        p = f"bert.encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s[p + "attention.output.dense.weight"] = (H, H)
+        s[p + "attention.output.dense.bias"] = (H,)
+        s[p + "attention.output.LayerNorm.weight"] = (H,)
+        s[p + "attention.output.LayerNorm.bias"] = (H,)
+        s[p + "intermediate.dense.weight"] = (I, H)
+        s[p + "intermediate.dense.bias"] = (I,)
+        s[p + "output.dense.weight"] = (H, I)
+        s[p + "output.dense.bias"] = (H,)
+        s[p + "output.LayerNorm.weight"] = (H,)
+        s[p + "output.LayerNorm.bias"] = (H,)
+    s["bert.pooler.dense.weight"] = (H, H)
+    s["bert.pooler.dense.bias"] = (H,)
+    s["classifier.weight"] = (cfg.num_labels, H)
+    s["classifier.bias"] = (cfg.num_labels,)
+    return s
+
+
+def state_dict_keys(cfg: BertConfig):
+    return list(state_dict_shapes(cfg).keys())
+
+
+def procedural_state_dict(cfg: BertConfig, seed: int = 0, weight_std: float = 0.02):
+    """name -> fp32 torch tensor. Linear/embedding weights and biases ~ N(0, weight_std);
+    LayerNorm gamma = 1 + 0.1 N(0,1), beta = 0.1 N(0,1) so the affine part is exercised."""
+    out = {}
+    for name, shape in state_dict_shapes(cfg).items():
+        g = np.random.Generator(np.random.Philox(key=[seed, zlib.crc32(name.encode())]))
+        x = g.standard_normal(shape, dtype=np.float32)
+        if "LayerNorm.weight" in name:
+            x = 1.0 + 0.1 * x
+        elif "LayerNorm.bias" in name:
+            x = 0.1 * x
+        else:
+            x = weight_std * x
+        out[name] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return out
