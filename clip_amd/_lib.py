@@ -1,0 +1,78 @@
+"""ctypes binding of libclip_amd.so (include/clip_amd.h).  There is no fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclip_amd.so")
+
+CLIP_OK, CLIP_ERR_ARG, CLIP_ERR_HIP, CLIP_ERR_STATE, CLIP_ERR_CAPACITY, CLIP_ERR_SEP_COUNT = 0, -1, -2, -3, -4, -5
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH = 0, 1, 2, 3
+
+
+class ClipConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "hidden_size", "num_layers", "num_heads",
+                                         "intermediate_size", "max_position", "type_vocab_size",
+                                         "num_labels")] + \
+               [("layer_norm_eps", C.c_float), ("max_tokens", C.c_int32), ("max_seqs", C.c_int32)]
+
+
+class ClipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libclip_amd error {code}: {msg}")
+        self.code = code
+
+
+_p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes; every symbol include/clip_amd.h declares (tests check the export list)
+SIGNATURES = {
+    "clip_create": [C.POINTER(ClipConfig), C.c_int, C.POINTER(_p)],
+    "clip_destroy": [_p],
+    "clip_load_weight": [_p, C.c_char_p, _p, _i64],
+    "clip_finalize_weights": [_p],
+    "clip_focus_index": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
+    "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
+    "clip_bce_loss": [_p, _p, _i32, _p, _p],
+    "clip_gemm_bf16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "clip_layernorm": [_p, _p, _p, _f, _p, _i32, _i32, _p],
+    "clip_embed_layernorm": [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_last_error": [],
+    "clip_abi_version": [],
+}
+
+_lib = None
+
+
+def load():
+    """Load the in-tree library (built by __graft_entry__.build() / make -C clip_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p if name == "clip_last_error" else C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != CLIP_OK:
+        raise ClipError(rc, load().clip_last_error().decode())
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

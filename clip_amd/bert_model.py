@@ -1,0 +1,270 @@
+"""Host-side mirror of the reference's model classes, backed by the HIP engine.
+
+Same names, call order and return shapes as /root/reference/sentclf/bert_model.py:
+    model = BertSequenceMultilabelClassificationContext.from_pretrained(local_dir)   # test_load.py:21
+    model.set_sep_token_id(102); model.set_n_context_sentences(2); model.set_task('multilabel')
+    model.load_state_dict(torch.load(path)); model.to('cuda'); model.eval()          # apply_bert_unlabeled.py:72-80,100
+    loss, logits = model(input_ids=..., attention_mask=..., token_type_ids=..., labels=...)
+
+Differences, all forced by the environment: from_pretrained takes a LOCAL directory (config.json +
+pytorch_model.bin | model.safetensors) — hub names cannot resolve offline; only inference is
+implemented (no autograd, dropout is the identity as in model.eval()); the arithmetic runs in
+libclip_amd.so on an MI355X and there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from .config import BertConfig
+from .weights import state_dict_shapes
+
+_IGNORED_KEYS = ("bert.embeddings.position_ids", "bert.embeddings.token_type_ids")
+
+
+def pack_padded(input_ids, attention_mask=None, token_type_ids=None, position_ids=None):
+    """[B,S] padded tensors -> packed int32 (ids, type_ids, pos_ids, cu_seqlens, max_len).
+    Tokens with attention_mask == 1 are kept, in row-major order; the reference's key-padding mask
+    (transformers modeling_bert.py:688-708) becomes the packing."""
+    B, S = input_ids.shape
+    dev = input_ids.device
+    mask = torch.ones((B, S), dtype=torch.bool, device=dev) if attention_mask is None \
+        else attention_mask.to(torch.bool)
+    lens = mask.sum(1, dtype=torch.int32)
+    cu = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    ids = input_ids[mask].to(torch.int32).contiguous()
+    if position_ids is None:
+        position_ids = torch.arange(S, device=dev).unsqueeze(0).expand(B, S)
+    else:
+        position_ids = position_ids.expand(B, S)
+    pos = position_ids[mask].to(torch.int32).contiguous()
+    tt = None if token_type_ids is None else token_type_ids[mask].to(torch.int32).contiguous()
+    lens_h = lens.cpu()
+    if int(lens_h.min()) < 1:
+        raise ValueError("every row needs at least one unmasked token")
+    return ids, tt, pos, cu, int(lens_h.max())
+
+
+class _EngineModel:
+    """Shared plumbing: config, weights, engine lifetime, packed forward."""
+    head_kind = 0
+
+    def __init__(self, config: BertConfig, max_tokens=65536, max_seqs=16384):
+        config.validate_for_device()
+        self.config = config
+        self.num_labels = config.num_labels
+        self.max_tokens, self.max_seqs = int(max_tokens), int(max_seqs)
+        self.task = "multilabel"
+        self.training = False
+        self.device = torch.device("cpu")
+        self._sd = None
+        self._engine = None
+
+    # ---- construction (test_load.py:21, apply_bert_unlabeled.py:65-70,78-79)
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kwargs):
+        if config is None:
+            config = BertConfig.from_pretrained(path)
+        model = cls(config, **{k: v for k, v in kwargs.items() if k in ("max_tokens", "max_seqs")})
+        st = os.path.join(path, "model.safetensors")
+        pt = os.path.join(path, "pytorch_model.bin")
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+            model.load_state_dict(load_file(st))
+        elif os.path.isfile(pt):
+            model.load_state_dict(torch.load(pt, map_location="cpu", weights_only=True))
+        else:
+            raise OSError(f"no model.safetensors / pytorch_model.bin under {path!r}")
+        return model
+
+    def save_pretrained(self, path):
+        from safetensors.torch import save_file
+        self.config.save_pretrained(path)
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(path, "model.safetensors"))
+
+    def load_state_dict(self, sd, strict=True):
+        shapes = state_dict_shapes(self.config)
+        sd = {k: v for k, v in sd.items() if k not in _IGNORED_KEYS}
+        missing = [k for k in shapes if k not in sd]
+        unexpected = [k for k in sd if k not in shapes]
+        if self.head_kind == 0:  # the context head never reads the pooler
+            missing = [k for k in missing if not k.startswith("bert.pooler.")]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        for k, v in sd.items():
+            if k in shapes and tuple(v.shape) != tuple(shapes[k]):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(shapes[k])}")
+        self._sd = {k: sd[k].detach().to("cpu", torch.float32).contiguous() for k in shapes if k in sd}
+        self._drop_engine()
+        return missing, unexpected
+
+    def state_dict(self):
+        if self._sd is None:
+            raise RuntimeError("no weights loaded")
+        return dict(self._sd)
+
+    # ---- setters (bert_model.py:23-32, 207-208)
+    def set_task(self, task):
+        self.task = task
+
+    # ---- nn.Module-style lifetime
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self.device:
+            self._drop_engine()
+            self.device = device
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("inference engine: training is out of scope")
+        return self
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            _lib.load().clip_destroy(self._engine)
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self._drop_engine()
+        except Exception:
+            pass
+
+    def _ensure_engine(self):
+        if self._engine is not None:
+            return self._engine
+        if self.device.type != "cuda":
+            raise RuntimeError("the model must be moved to an MI355X first (model.to('cuda')); "
+                               "clip_amd has no CPU execution path")
+        if self._sd is None:
+            raise RuntimeError("no weights loaded (from_pretrained / load_state_dict)")
+        lib = _lib.load()
+        c = self.config
+        cc = _lib.ClipConfig(c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
+                             c.intermediate_size, c.max_position_embeddings, c.type_vocab_size,
+                             c.num_labels, c.layer_norm_eps, self.max_tokens, self.max_seqs)
+        h = C.c_void_p()
+        _lib.check(lib.clip_create(C.byref(cc), self.device.index, C.byref(h)))
+        try:
+            for k, v in self._sd.items():
+                _lib.check(lib.clip_load_weight(h, k.encode(), C.c_void_p(v.data_ptr()), v.numel()))
+            _lib.check(lib.clip_finalize_weights(h))
+        except Exception:
+            lib.clip_destroy(h)
+            raise
+        self._engine = h
+        return h
+
+    # ---- the packed fast path (used by clip_amd.scoring) ------------------------------------
+    def focus_index(self, ids, cu_seqlens):
+        raise NotImplementedError
+
+    def forward_packed(self, ids, type_ids, pos_ids, cu_seqlens, max_seqlen, focus=None, check=True):
+        """ids/type_ids/pos_ids int32 [T] and cu_seqlens int32 [n+1] on this model's device.
+        Returns fp32 logits [n, num_labels]."""
+        h = self._ensure_engine()
+        lib = _lib.load()
+        n, T = cu_seqlens.numel() - 1, ids.numel()
+        if focus is None:
+            focus = self.focus_index(ids, cu_seqlens, check=check)
+        logits = torch.empty((n, self.num_labels), dtype=torch.float32, device=ids.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.clip_forward_packed(h, _lib.ptr(ids), _lib.ptr(type_ids), _lib.ptr(pos_ids),
+                                               _lib.ptr(cu_seqlens), _lib.ptr(focus), n, T, int(max_seqlen),
+                                               self.head_kind, _lib.ptr(logits), _lib.stream_ptr()))
+        return logits
+
+    def _focus(self, ids, cu_seqlens, n_ctx, sep_id, check):
+        lib = _lib.load()
+        n = cu_seqlens.numel() - 1
+        focus = torch.empty(n, dtype=torch.int32, device=ids.device)
+        err = torch.zeros(1, dtype=torch.int32, device=ids.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.clip_focus_index(_lib.ptr(ids), _lib.ptr(cu_seqlens), n, int(sep_id), int(n_ctx),
+                                            _lib.ptr(focus), _lib.ptr(err), _lib.stream_ptr()))
+        if check and n_ctx >= 0 and int(err.item()) != 0:
+            # reference: prints and returns None, then classifier(None) raises (bert_model.py:51-55,91)
+            print("error when pulling out end of sentence indices: a row does not hold exactly "
+                  f"{2 * n_ctx + 1} [SEP] tokens")
+            raise TypeError("focus-sentence representation is None: wrong [SEP] count in a row")
+        return focus
+
+    # ---- the reference's padded forward ------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, labels=None, output_attentions=None,
+                output_hidden_states=None, doc_positions=None):
+        if head_mask is not None or inputs_embeds is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("head_mask / inputs_embeds / attentions / hidden states are not on the scoring path")
+        if doc_positions is not None and len(doc_positions) > 0:
+            raise NotImplementedError("doc_position feature is not on the scoring path")
+        if input_ids.device != self.device:
+            raise RuntimeError(f"inputs on {input_ids.device}, model on {self.device}")
+        ids, tt, pos, cu, max_len = pack_padded(input_ids, attention_mask, token_type_ids, position_ids)
+        B = input_ids.shape[0]
+        if ids.numel() > self.max_tokens or B > self.max_seqs:
+            raise _lib.ClipError(_lib.CLIP_ERR_CAPACITY,
+                                 f"batch of {B} rows / {ids.numel()} tokens exceeds the engine workspace "
+                                 f"({self.max_seqs} / {self.max_tokens}); construct with larger max_tokens/max_seqs")
+        logits = self.forward_packed(ids, tt, pos, cu, max_len)
+        if labels is None:
+            return (logits,)
+        if self.task != "multilabel":
+            raise NotImplementedError("only task='multilabel' is on the scoring path")
+        lab = labels.to(self.device, torch.float32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().clip_bce_loss(_lib.ptr(logits), _lib.ptr(lab), logits.numel(),
+                                                 _lib.ptr(loss), _lib.stream_ptr()))
+        return loss[0], logits
+
+    __call__ = forward
+
+
+class BertSequenceMultilabelClassificationContext(_EngineModel):
+    """ref: sentclf/bert_model.py:8-103 — BERT over [CLS] ctx [SEP] .. focus [SEP] .. ctx [SEP],
+    hidden state at the focus sentence's closing [SEP] -> Linear(H, num_labels)."""
+    head_kind = 0
+
+    def __init__(self, config, **kw):
+        super().__init__(config, **kw)
+        self.sep_token_id = None
+        self.n_context_sentences = None
+
+    def set_sep_token_id(self, sep_token_id):
+        self.sep_token_id = int(sep_token_id)
+
+    def set_n_context_sentences(self, n_context_sentences):
+        self.n_context_sentences = int(n_context_sentences)
+
+    def focus_index(self, ids, cu_seqlens, check=True):
+        if self.sep_token_id is None or self.n_context_sentences is None:
+            raise AttributeError("call set_sep_token_id() and set_n_context_sentences() first")
+        return self._focus(ids, cu_seqlens, self.n_context_sentences, self.sep_token_id, check)
+
+
+class BertForSequenceMultilabelClassification(_EngineModel):
+    """ref: sentclf/bert_model.py:189-251 — BertModel pooler output -> Linear(H, num_labels)."""
+    head_kind = 1
+
+    def focus_index(self, ids, cu_seqlens, check=True):
+        return self._focus(ids, cu_seqlens, -1, 0, check)
+
+
+def args_to_model(n_context_sentences):
+    """ref: sentclf/bert.py:361-366"""
+    if n_context_sentences == 0:
+        return BertForSequenceMultilabelClassification
+    return BertSequenceMultilabelClassificationContext

@@ -1,0 +1,202 @@
+// Varlen (packed, cu_seqlens) bidirectional self-attention, head_dim 64, bf16 MFMA, fp32 softmax.
+// Restates softmax(Q K^T / sqrt(d) + key-padding mask) V of transformers BertSelfAttention
+// (modeling_bert.py:164-203, math :111-136) for the reference's sentclf/bert_model.py:79-88.
+// Packing replaces the padding mask (keys past a sequence's end do not exist); 1/sqrt(64) is
+// folded exactly into Wq/bq at weight load.
+//
+// Workgroup = 4 waves = one 128-row q tile of one (sequence, head); each wave owns 32 q rows.
+// Per 64-key tile:  S^T = K Q^T  (32x32x16 MFMA, key on rows, q on the lane -> a q row's softmax
+// statistics are lane-local), P = exp2(S^T - m) converted in place to the B operand of
+// O^T = V^T P^T (the accumulator-as-operand k order of the guide, §3), V^T fragments come from
+// the row-major V tile in LDS through ds_read_b64_tr_b16.  K/V tiles are register-staged
+// (next tile's global loads are issued before the current tile's MFMAs, written to LDS after
+// the barrier), K swizzled for ds_read_b128, V swizzled for the transposed read.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;       // head dim
+constexpr int KT = 64;       // keys per tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
+                                                        const int32_t* __restrict__ cu,
+                                                        bf16_t* __restrict__ ctx, int hidden,
+                                                        int q_tiles) {
+  __shared__ __attribute__((aligned(16))) char k_lds[KT * 128];
+  __shared__ __attribute__((aligned(16))) char v_lds[KT * 128];
+
+  const int seq = blockIdx.x / q_tiles, head = blockIdx.y;
+  const int beg = cu[seq];
+  const int len = cu[seq + 1] - beg;
+  const int q_tile0 = (blockIdx.x - seq * q_tiles) * 128;
+  if (q_tile0 >= len) return;  // workgroup-uniform
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int ld = 3 * hidden;  // qkv row stride (elements)
+  const bf16_t* qbase = qkv + (size_t)beg * ld + head * HD;
+  const bf16_t* kbase = qbase + hidden;
+  const bf16_t* vbase = qbase + 2 * hidden;
+
+  const int q0 = q_tile0 + w * 32;
+  const bool wave_live = q0 < len;  // wave-uniform
+
+  // Q^T fragments (B operand of S^T): lane holds Q[q0 + l31][16 s + 8 h + j]
+  bf16x8_t qf[4];
+  {
+    const int qr = min(q0 + l31, len - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = *reinterpret_cast<const bf16x8_t*>(qbase + (size_t)qr * ld + 16 * s + 8 * h);
+  }
+
+  // staging map: thread -> (row, chunk) for two 16-B chunks of K and of V per tile
+  const int st_row = tid >> 3, st_chunk = tid & 7;  // rows st_row and st_row + 32
+  uint4 kreg[2], vreg[2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = kv0 + st_row + 32 * i;
+      if (r < len) {
+        kreg[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)r * ld + st_chunk * 8);
+        vreg[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)r * ld + st_chunk * 8);
+      } else {  // keys past the end: zero (masked below; V must not carry NaN into 0 * V)
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        vreg[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = st_row + 32 * i;
+      *reinterpret_cast<uint4*>(k_lds + r * 128 + swz128(r, st_chunk) * 16) = kreg[i];
+      *reinterpret_cast<uint4*>(v_lds + r * 128 + swz_v(r, st_chunk) * 16) = vreg[i];
+    }
+  };
+
+  f32x16_t o[2];  // O^T[d][q]: d = 32 db + (reg&3) + 8 (reg>>2) + 4 h, q on the lane
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running max (log2 domain, shared by both halves), partial sum
+
+  const int n_tiles = (len + KT - 1) / KT;
+  load_tile(0);
+  for (int t = 0; t < n_tiles; ++t) {
+    __syncthreads();  // previous tile's LDS reads done
+    store_tile();
+    __syncthreads();
+    if (t + 1 < n_tiles) load_tile((t + 1) * KT);
+    if (!wave_live) continue;
+
+    const int kv0 = t * KT;
+    // ---- S^T = K Q^T for the two 32-key blocks
+    f32x16_t s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const int row = kb * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+            k_lds + row * 128 + swz128(row, 2 * ks + h) * 16);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask keys past the end, tile max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = key < len ? s[kb][r] * LOG2E : -INFINITY;
+        s[kb][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+    // ---- P = exp2(S - m), O^T += V^T P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = exp2f(s[kb][r] - m_new);
+        l_run += p[r];
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        bf16x8_t pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)p[8 * ss + j];
+        // element j of half h <-> key 32 kb + 16 ss + 8 (j>>2) + 4 h + (j&3)
+        const int key0 = kb * 32 + 16 * ss + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          // transposed read: 16-lane group g reads rows key0.. key0+3, cols 32 db + 16 (g&1) ..+15;
+          // lane i = 4 qq + pp of the group supplies &V[key0 + qq][col0 + 4 pp]
+          const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+          const int col0 = 32 * db + 16 * ((lane >> 4) & 1) + 4 * pp;  // element column
+          const int ra = key0 + qq, rb = key0 + 8 + qq;
+          const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(v_lds + ra * 128 +
+                                                           swz_v(ra, col0 >> 3) * 16 + (col0 & 7) * 2));
+          const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(v_lds + rb * 128 +
+                                                           swz_v(rb, col0 >> 3) * 16 + (col0 & 7) * 2));
+          s16x8_t vv;
+          vv[0] = va[0]; vv[1] = va[1]; vv[2] = va[2]; vv[3] = va[3];
+          vv[4] = vb[0]; vv[5] = vb[1]; vv[6] = vb[2]; vv[7] = vb[3];
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8_t*>(&vv), pf,
+                                                          o[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (!wave_live) return;
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  const int q = q0 + l31;
+  if (q < len) {
+    bf16_t* dst = ctx + (size_t)(beg + q) * hidden + head * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * db + 8 * g + 4 * h;
+        *reinterpret_cast<uint2*>(dst + d) =
+            make_uint2(pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                       pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+      }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
+                            int max_seqlen, int n_heads, int hidden, hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;
+  const int q_tiles = (max_seqlen + 127) / 128;
+  hipLaunchKernelGGL(attention_kernel, dim3(q_tiles * n_seqs, n_heads), dim3(256), 0, st, qkv,
+                     cu_seqlens, ctx, hidden, q_tiles);
+  return hipGetLastError();
+}

@@ -1,0 +1,359 @@
+// C ABI of libclip_amd.so (include/clip_amd.h): engine object = device weights + activation
+// workspace; clip_forward_packed chains the kernels of one BERT(+Context) forward on one stream.
+#include <map>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <cmath>
+
+#include "common.h"
+#include "kernels.h"
+#include "../../include/clip_amd.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return fail(CLIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct LayerW {
+  bf16_t *wqkv, *wo, *wi, *wo2;
+  float *bqkv, *bo, *bi, *bo2, *ln1g, *ln1b, *ln2g, *ln2b;
+};
+
+}  // namespace
+
+struct clip_engine {
+  clip_config cfg;
+  int device;
+  bool finalized = false;
+  std::map<std::string, std::vector<float>> host_w;  // until finalize
+  std::vector<void*> allocs;
+  // weights
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
+  std::vector<LayerW> layers;
+  bf16_t* wpool = nullptr;
+  float *bpool = nullptr, *wcls = nullptr, *bcls = nullptr;
+  // workspace
+  bf16_t *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
+         *pooled = nullptr;
+  float* preln = nullptr;
+};
+
+namespace {
+
+int dev_alloc(clip_engine* e, void** p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes));
+  e->allocs.push_back(*p);
+  return CLIP_OK;
+}
+
+int upload_f32(clip_engine* e, const std::vector<float>& h, float** d) {
+  int rc = dev_alloc(e, (void**)d, h.size() * 4);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  return CLIP_OK;
+}
+
+int upload_bf16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scale_first = 1.f,
+                size_t n_first = 0) {
+  std::vector<uint16_t> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = host_f32_to_bf16(i < n_first ? h[i] * scale_first : h[i]);
+  int rc = dev_alloc(e, (void**)d, n * 2);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*d, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CLIP_OK;
+}
+
+const std::vector<float>* find(clip_engine* e, const std::string& k, size_t numel) {
+  auto it = e->host_w.find(k);
+  if (it == e->host_w.end()) {
+    fail(CLIP_ERR_STATE, "missing weight '%s'", k.c_str());
+    return nullptr;
+  }
+  if (it->second.size() != numel) {
+    fail(CLIP_ERR_ARG, "weight '%s' has %zu elements, expected %zu", k.c_str(), it->second.size(),
+         numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* clip_last_error(void) { return g_err.c_str(); }
+int clip_abi_version(void) { return 1; }
+
+int clip_create(const clip_config* c, int device_id, clip_engine** out) {
+  if (!c || !out) return fail(CLIP_ERR_ARG, "clip_create: null argument");
+  if (c->hidden_size != c->num_heads * 64)
+    return fail(CLIP_ERR_ARG, "clip_create: head_dim must be 64 (hidden %d, heads %d)",
+                c->hidden_size, c->num_heads);
+  switch (c->hidden_size) {
+    case 128: case 256: case 384: case 512: case 768: case 1024: break;
+    default: return fail(CLIP_ERR_ARG, "clip_create: unsupported hidden_size %d", c->hidden_size);
+  }
+  if (c->intermediate_size % 64 || c->num_labels < 1 || c->num_labels > 8 || c->num_layers < 1)
+    return fail(CLIP_ERR_ARG, "clip_create: unsupported geometry");
+  if (c->max_tokens < 1 || c->max_seqs < 1) return fail(CLIP_ERR_ARG, "clip_create: empty workspace");
+  HIP_TRY(hipSetDevice(device_id));
+  clip_engine* e = new clip_engine();
+  e->cfg = *c;
+  e->device = device_id;
+  const size_t Tp = ((size_t)c->max_tokens + 127) / 128 * 128, H = c->hidden_size,
+               I = c->intermediate_size, S = ((size_t)c->max_seqs + 127) / 128 * 128;
+  int rc = 0;
+  rc = rc ? rc : dev_alloc(e, (void**)&e->x, Tp * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->qkv, Tp * 3 * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->ctx, Tp * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->mid, Tp * I * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->preln, Tp * H * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->rows, S * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pooled, S * H * 2);
+  if (rc) {
+    clip_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return CLIP_OK;
+}
+
+int clip_destroy(clip_engine* e) {
+  if (!e) return CLIP_OK;
+  hipSetDevice(e->device);
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+  return CLIP_OK;
+}
+
+int clip_load_weight(clip_engine* e, const char* name, const float* host_data, int64_t numel) {
+  if (!e || !name || !host_data || numel <= 0) return fail(CLIP_ERR_ARG, "clip_load_weight: bad argument");
+  if (e->finalized) return fail(CLIP_ERR_STATE, "clip_load_weight: weights already finalized");
+  const std::string k(name);
+  const bool known = k.rfind("bert.embeddings.", 0) == 0 || k.rfind("bert.encoder.layer.", 0) == 0 ||
+                     k.rfind("bert.pooler.dense.", 0) == 0 || k.rfind("classifier.", 0) == 0;
+  if (!known || k == "bert.embeddings.position_ids" || k == "bert.embeddings.token_type_ids")
+    return fail(CLIP_ERR_ARG, "clip_load_weight: '%s' is not a parameter of this model", name);
+  e->host_w[k].assign(host_data, host_data + numel);
+  return CLIP_OK;
+}
+
+int clip_finalize_weights(clip_engine* e) {
+  if (!e) return fail(CLIP_ERR_ARG, "clip_finalize_weights: null engine");
+  if (e->finalized) return CLIP_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const clip_config& c = e->cfg;
+  const size_t H = c.hidden_size, I = c.intermediate_size;
+  int rc;
+#define GET(var, key, n)                       \
+  const std::vector<float>* var = find(e, key, n); \
+  if (!var) return g_err.rfind("missing", 0) == 0 ? CLIP_ERR_STATE : CLIP_ERR_ARG;
+  {
+    GET(w, "bert.embeddings.word_embeddings.weight", (size_t)c.vocab_size * H);
+    GET(p, "bert.embeddings.position_embeddings.weight", (size_t)c.max_position * H);
+    GET(t, "bert.embeddings.token_type_embeddings.weight", (size_t)c.type_vocab_size * H);
+    GET(g, "bert.embeddings.LayerNorm.weight", H);
+    GET(b, "bert.embeddings.LayerNorm.bias", H);
+    if ((rc = upload_f32(e, *w, &e->word)) || (rc = upload_f32(e, *p, &e->pos)) ||
+        (rc = upload_f32(e, *t, &e->type)) || (rc = upload_f32(e, *g, &e->embg)) ||
+        (rc = upload_f32(e, *b, &e->embb)))
+      return rc;
+  }
+  e->layers.resize(c.num_layers);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string p = "bert.encoder.layer." + std::to_string(i) + ".";
+    LayerW& L = e->layers[i];
+    GET(wq, p + "attention.self.query.weight", H * H);
+    GET(wk, p + "attention.self.key.weight", H * H);
+    GET(wv, p + "attention.self.value.weight", H * H);
+    GET(bq, p + "attention.self.query.bias", H);
+    GET(bk, p + "attention.self.key.bias", H);
+    GET(bv, p + "attention.self.value.bias", H);
+    // fused [3H, H] weight; 1/sqrt(64) = 0.125 folded into the query rows (exact: power of two)
+    std::vector<float> wqkv(3 * H * H), bqkv(3 * H);
+    memcpy(wqkv.data(), wq->data(), H * H * 4);
+    memcpy(wqkv.data() + H * H, wk->data(), H * H * 4);
+    memcpy(wqkv.data() + 2 * H * H, wv->data(), H * H * 4);
+    for (size_t j = 0; j < H; ++j) {
+      bqkv[j] = (*bq)[j] * 0.125f;
+      bqkv[H + j] = (*bk)[j];
+      bqkv[2 * H + j] = (*bv)[j];
+    }
+    if ((rc = upload_bf16(e, wqkv.data(), wqkv.size(), &L.wqkv, 0.125f, H * H))) return rc;
+    if ((rc = upload_f32(e, bqkv, &L.bqkv))) return rc;
+    GET(wo, p + "attention.output.dense.weight", H * H);
+    GET(bo, p + "attention.output.dense.bias", H);
+    GET(g1, p + "attention.output.LayerNorm.weight", H);
+    GET(b1, p + "attention.output.LayerNorm.bias", H);
+    GET(wi, p + "intermediate.dense.weight", I * H);
+    GET(bi, p + "intermediate.dense.bias", I);
+    GET(w2, p + "output.dense.weight", H * I);
+    GET(b2, p + "output.dense.bias", H);
+    GET(g2, p + "output.LayerNorm.weight", H);
+    GET(bb2, p + "output.LayerNorm.bias", H);
+    if ((rc = upload_bf16(e, wo->data(), wo->size(), &L.wo)) || (rc = upload_f32(e, *bo, &L.bo)) ||
+        (rc = upload_f32(e, *g1, &L.ln1g)) || (rc = upload_f32(e, *b1, &L.ln1b)) ||
+        (rc = upload_bf16(e, wi->data(), wi->size(), &L.wi)) || (rc = upload_f32(e, *bi, &L.bi)) ||
+        (rc = upload_bf16(e, w2->data(), w2->size(), &L.wo2)) || (rc = upload_f32(e, *b2, &L.bo2)) ||
+        (rc = upload_f32(e, *g2, &L.ln2g)) || (rc = upload_f32(e, *bb2, &L.ln2b)))
+      return rc;
+  }
+  {
+    GET(wc, "classifier.weight", (size_t)c.num_labels * H);
+    GET(bc, "classifier.bias", (size_t)c.num_labels);
+    if ((rc = upload_f32(e, *wc, &e->wcls)) || (rc = upload_f32(e, *bc, &e->bcls))) return rc;
+    // the pooler is only needed by the sentence-only head; tolerate its absence
+    auto it = e->host_w.find("bert.pooler.dense.weight");
+    auto ib = e->host_w.find("bert.pooler.dense.bias");
+    if (it != e->host_w.end() && ib != e->host_w.end()) {
+      if (it->second.size() != H * H || ib->second.size() != H)
+        return fail(CLIP_ERR_ARG, "pooler weight has the wrong size");
+      if ((rc = upload_bf16(e, it->second.data(), H * H, &e->wpool)) ||
+          (rc = upload_f32(e, ib->second, &e->bpool)))
+        return rc;
+    }
+  }
+#undef GET
+  e->host_w.clear();
+  e->finalized = true;
+  return CLIP_OK;
+}
+
+int clip_focus_index(const int32_t* ids, const int32_t* cu, int32_t n_seqs, int32_t sep_id,
+                     int32_t n_ctx, int32_t* focus, int32_t* err, void* stream) {
+  if (!ids || !cu || !focus || !err || n_seqs < 0) return fail(CLIP_ERR_ARG, "clip_focus_index: bad argument");
+  HIP_TRY(launch_focus_index(ids, cu, n_seqs, sep_id, n_ctx, focus, err, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_ids,
+                        const int32_t* pos_ids, const int32_t* cu, const int32_t* focus,
+                        int32_t n_seqs, int32_t T, int32_t max_seqlen, int32_t head_kind,
+                        float* logits, void* stream) {
+  if (!e || !ids || !pos_ids || !cu || !focus || !logits)
+    return fail(CLIP_ERR_ARG, "clip_forward_packed: null argument");
+  if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_packed: weights not finalized");
+  if (n_seqs == 0 || T == 0) return CLIP_OK;
+  if (n_seqs < 0 || T < 0 || max_seqlen < 1 || max_seqlen > e->cfg.max_position)
+    return fail(CLIP_ERR_ARG, "clip_forward_packed: bad sizes (n_seqs %d, tokens %d, max_seqlen %d)",
+                n_seqs, T, max_seqlen);
+  if (n_seqs > e->cfg.max_seqs || T > e->cfg.max_tokens)
+    return fail(CLIP_ERR_CAPACITY, "clip_forward_packed: %d seqs / %d tokens exceed the workspace (%d / %d)",
+                n_seqs, T, e->cfg.max_seqs, e->cfg.max_tokens);
+  if (head_kind == 1 && !e->wpool)
+    return fail(CLIP_ERR_STATE, "clip_forward_packed: pooler weights were not loaded");
+  if (head_kind != 0 && head_kind != 1) return fail(CLIP_ERR_ARG, "clip_forward_packed: head_kind");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  const clip_config& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size;
+
+  HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
+                          c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
+                          c.type_vocab_size, st));
+  GemmArgs g;
+  for (int i = 0; i < c.num_layers; ++i) {
+    const LayerW& L = e->layers[i];
+    g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+    HIP_TRY(launch_gemm(g, st));
+    HIP_TRY(launch_attention(e->qkv, cu, e->ctx, n_seqs, max_seqlen, c.num_heads, H, st));
+    g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, T, H, H, H, H, H, H, EPI_BIAS_RES, true};
+    HIP_TRY(launch_gemm(g, st));
+    HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st));
+    g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, T, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+    HIP_TRY(launch_gemm(g, st));
+    g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, T, H, I, I, I, H, H, EPI_BIAS_RES, true};
+    HIP_TRY(launch_gemm(g, st));
+    HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st));
+  }
+  if (head_kind == 0) {
+    HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
+  } else {
+    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
+    g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
+                 EPI_BIAS_TANH, false};
+    HIP_TRY(launch_gemm(g, st));
+    HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
+                              c.num_labels, st));
+  }
+  return CLIP_OK;
+}
+
+int clip_epilogue(const float* logits, const double* thr, float any_thresh, int32_t n, int32_t L,
+                  float* probs, float* max_score, uint8_t* labels, uint8_t* keep, void* stream) {
+  if (!logits || n < 0 || L < 1 || L > 8 || (labels && !thr))
+    return fail(CLIP_ERR_ARG, "clip_epilogue: bad argument");
+  HIP_TRY(launch_epilogue(logits, thr, any_thresh, n, L, probs, max_score, labels, keep,
+                          (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_bce_loss(const float* logits, const float* targets, int32_t count, float* loss,
+                  void* stream) {
+  if (!logits || !targets || !loss || count < 1) return fail(CLIP_ERR_ARG, "clip_bce_loss: bad argument");
+  HIP_TRY(launch_bce_loss(logits, targets, count, loss, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res,
+                   void* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                   int32_t ldo, int32_t ldres, int32_t epi, int32_t out_f32, void* stream) {
+  GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, out_f32 != 0};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_attention_varlen(const uint16_t* qkv, const int32_t* cu, uint16_t* ctx, int32_t n_seqs,
+                          int32_t max_seqlen, int32_t n_heads, int32_t hidden, void* stream) {
+  if (!qkv || !cu || !ctx || n_seqs < 0) return fail(CLIP_ERR_ARG, "clip_attention_varlen: bad argument");
+  HIP_TRY(launch_attention(qkv, cu, ctx, n_seqs, max_seqlen, n_heads, hidden, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_layernorm(const float* x, const float* gamma, const float* beta, float eps, uint16_t* out,
+                   int32_t T, int32_t H, void* stream) {
+  if (!x || !gamma || !beta || !out || T < 0) return fail(CLIP_ERR_ARG, "clip_layernorm: bad argument");
+  HIP_TRY(launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_embed_layernorm(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
+                         const float* word, const float* pos, const float* type, const float* gamma,
+                         const float* beta, float eps, uint16_t* out, int32_t T, int32_t H,
+                         int32_t vocab, int32_t max_pos, int32_t type_vocab, void* stream) {
+  if (!ids || !pos_ids || !word || !pos || !type || !gamma || !beta || !out || T < 0)
+    return fail(CLIP_ERR_ARG, "clip_embed_layernorm: bad argument");
+  HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H,
+                          vocab, max_pos, type_vocab, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Internal launcher interface between the kernel files and the C-ABI (engine.hip).
+#pragma once
+#include "common.h"
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3 };
+
+struct GemmArgs {
+  const bf16_t* A;    // [M, K] activations, row stride lda (elements)
+  const bf16_t* W;    // [N, K] weight, row stride ldw
+  const float* bias;  // [N]
+  const bf16_t* res;  // [M, N] residual (EPI_BIAS_RES), row stride ldres
+  void* out;          // [M, N] bf16 or f32, row stride ldo
+  int M, N, K, lda, ldw, ldo, ldres;
+  int epi;
+  bool out_f32;
+};
+const char* gemm_check(const GemmArgs& g);
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// varlen self-attention over packed sequences; qkv [T, 3H] bf16 (q | k | v, heads of 64),
+// q pre-scaled by 1/sqrt(64); ctx [T, H] bf16. One workgroup per (128-row q tile, sequence, head).
+// q_rows (optional, [n_seqs]): attend only from that one token per sequence (focus-only last
+// layer) and write row s of ctx.
+hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
+                            int max_seqlen, int n_heads, int hidden, hipStream_t st);
+
+// out_bf16[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]])
+hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
+                           const float* word, const float* pos, const float* type,
+                           const float* gamma, const float* beta, float eps, bf16_t* out, int T,
+                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st);
+// out_bf16[t] = LayerNorm(x_f32[t])
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                            bf16_t* out, int T, int H, hipStream_t st);
+// dst[i] = src[rows[i]]  (bf16 rows of H)
+hipError_t launch_gather_rows(const bf16_t* src, const int32_t* rows, bf16_t* dst, int n, int H,
+                              hipStream_t st);
+// logits[i] = Wc . x[rows ? rows[i] : i] + bc     (Wc [L,H] f32, x bf16)
+hipError_t launch_classifier(const bf16_t* x, const int32_t* rows, const float* Wc,
+                             const float* bc, float* logits, int n, int H, int L, hipStream_t st);
+// focus[s] = packed token index of the (n_ctx+1)-th sep of sequence s (or of its first token when
+// n_ctx < 0: the [CLS] row); err[0] |= 1 if any sequence does not hold exactly 2*n_ctx+1 seps
+hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
+                              int sep_id, int n_ctx, int32_t* focus, int32_t* err,
+                              hipStream_t st);
+// fused scoring epilogue (ref: apply_bert_unlabeled.py:111-124, test_load.py:37-38)
+hipError_t launch_epilogue(const float* logits, const double* label_thresh, float any_thresh,
+                           int n, int L, float* probs, float* max_score, uint8_t* labels,
+                           uint8_t* keep, hipStream_t st);
+// mean over all elements of BCE-with-logits (ref: bert_model.py:97)
+hipError_t launch_bce_loss(const float* logits, const float* targets, int count, float* loss,
+                           hipStream_t st);

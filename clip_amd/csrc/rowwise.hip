@@ -1,0 +1,304 @@
+// Row-wise (HBM-bound) kernels of the scoring path: embedding gather + LayerNorm, LayerNorm,
+// focus-[SEP] index, row gather, classifier head, fused sigmoid/threshold/max epilogue, BCE loss.
+// One 64-lane wave per row; all reductions are wave shuffles (no LDS, no atomics).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> { typedef float4 type; };
+template <>
+struct VecT<2> { typedef float2 type; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float* dst) {
+  typename VecT<VEC>::type v = *reinterpret_cast<const typename VecT<VEC>::type*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) dst[i] = f[i];
+}
+
+// normalise the NIT*VEC values a lane holds and store them as bf16
+template <int VEC, int NIT>
+__device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gamma,
+                                          const float* beta, float eps, bf16_t* out, int H,
+                                          int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s += x[it][v];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float d = x[it][v] - mean;
+      q += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (it * 64 + lane) * VEC;
+    float g[VEC], b[VEC];
+    load_vec<VEC>(gamma + e, g);
+    load_vec<VEC>(beta + e, b);
+    float y[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) y[v] = (x[it][v] - mean) * rstd * g[v] + b[v];
+    if (VEC == 4) {
+      *reinterpret_cast<uint2*>(out + e) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+    } else {
+      *reinterpret_cast<uint32_t*>(out + e) = pack_bf16x2(y[0], y[1]);
+    }
+  }
+}
+
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ xin,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        bf16_t* __restrict__ out, int T, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  float x[NIT][VEC];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
+  ln_finish<VEC, NIT>(x, gamma, beta, eps, out + (size_t)row * H, H, lane);
+}
+
+// BertEmbeddings.forward (transformers modeling_bert.py:68-108): word + token_type + position
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ type_ids,
+    const int32_t* __restrict__ pos_ids, const float* __restrict__ word,
+    const float* __restrict__ pos, const float* __restrict__ type,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    bf16_t* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  // ids are validated on the host side of the ABI; clamp anyway so a bad id cannot fault the GPU
+  const int id = min(max(ids[row], 0), vocab - 1);
+  const int ty = type_ids ? min(max(type_ids[row], 0), type_vocab - 1) : 0;
+  const int po = min(max(pos_ids[row], 0), max_pos - 1);
+  float x[NIT][VEC];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (it * 64 + lane) * VEC;
+    float a[VEC], b[VEC], c[VEC];
+    load_vec<VEC>(word + (size_t)id * H + e, a);
+    load_vec<VEC>(type + (size_t)ty * H + e, b);
+    load_vec<VEC>(pos + (size_t)po * H + e, c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x[it][v] = (a[v] + b[v]) + c[v];
+  }
+  ln_finish<VEC, NIT>(x, gamma, beta, eps, out + (size_t)row * H, H, lane);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src,
+                                                          const int32_t* __restrict__ rows,
+                                                          bf16_t* __restrict__ dst, int n, int H) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)rows[i] * H);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * H);
+  for (int c = lane; c < H / 8; c += 64) d[c] = s[c];
+}
+
+// classifier Linear(H -> L) on one row per wave (ref: sentclf/bert_model.py:91,239)
+__global__ __launch_bounds__(256) void classifier_kernel(const bf16_t* __restrict__ x,
+                                                         const int32_t* __restrict__ rows,
+                                                         const float* __restrict__ Wc,
+                                                         const float* __restrict__ bc,
+                                                         float* __restrict__ logits, int n, int H,
+                                                         int L) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const bf16_t* xr = x + (size_t)(rows ? rows[i] : i) * H;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int e = lane * 2; e < H; e += 128) {
+    const uint32_t xv = *reinterpret_cast<const uint32_t*>(xr + e);
+    const float x0 = __uint_as_float(xv << 16), x1 = __uint_as_float(xv & 0xffff0000u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < L) {
+        const float2 wv = *reinterpret_cast<const float2*>(Wc + (size_t)j * H + e);
+        acc[j] += x0 * wv.x + x1 * wv.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < L) {
+      const float s = wave_sum(acc[j]);
+      if (lane == 0) logits[(size_t)i * L + j] = s + bc[j];
+    }
+  }
+}
+
+// ref: sentclf/bert_model.py:52 — where(input_ids == sep)[1].reshape(-1, 2n+1)[:, n], per row
+__global__ __launch_bounds__(64) void focus_index_kernel(const int32_t* __restrict__ ids,
+                                                         const int32_t* __restrict__ cu, int n_seqs,
+                                                         int sep_id, int n_ctx,
+                                                         int32_t* __restrict__ focus,
+                                                         int32_t* __restrict__ err) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int beg = cu[s], end = cu[s + 1];
+  if (n_ctx < 0) {  // sentence-only model pools token 0
+    if (lane == 0) focus[s] = beg;
+    return;
+  }
+  int count = 0, found = -1;
+  for (int t0 = beg; t0 < end; t0 += 64) {
+    const int t = t0 + lane;
+    const bool hit = t < end && ids[t] == sep_id;
+    unsigned long long m = __ballot(hit);
+    const int c = __popcll(m);
+    if (found < 0 && count + c > n_ctx) {
+      int k = n_ctx - count;  // k-th set bit (0-based)
+      unsigned long long mm = m;
+      while (k-- > 0) mm &= mm - 1;
+      found = t0 + __ffsll((long long)mm) - 1;
+    }
+    count += c;
+  }
+  if (lane == 0) {
+    focus[s] = found < 0 ? beg : found;
+    if (count != 2 * n_ctx + 1) atomicOr(err, 1);
+  }
+}
+
+// 8 lanes per sentence (lane j<L holds label j), wave-shuffle max / any over the label axis.
+__global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__ logits,
+                                                       const double* __restrict__ label_thresh,
+                                                       float any_thresh, int n, int L,
+                                                       float* __restrict__ probs,
+                                                       float* __restrict__ max_score,
+                                                       uint8_t* __restrict__ labels,
+                                                       uint8_t* __restrict__ keep) {
+  const int g = blockIdx.x * 32 + (threadIdx.x >> 3);  // sentence
+  const int j = threadIdx.x & 7;                       // label slot
+  const bool live = g < n && j < L;
+  float p = -1.0f;  // below every probability
+  if (live) {
+    const float x = logits[(size_t)g * L + j];
+    p = 1.0f / (1.0f + expf(-x));  // torch.sigmoid in fp32
+    if (probs) probs[(size_t)g * L + j] = p;
+    if (labels) labels[(size_t)g * L + j] = label_thresh ? ((double)p > label_thresh[j]) : 0;
+  }
+  int any = live && (p > any_thresh);
+  float m = p;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    any |= __shfl_xor(any, o, 64);
+  }
+  if (g < n && j == 0) {
+    if (max_score) max_score[g] = m;
+    if (keep) keep[g] = (uint8_t)any;
+  }
+}
+
+__global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__ logits,
+                                                       const float* __restrict__ targets,
+                                                       int count, float* __restrict__ loss) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) {
+    const float x = logits[i], y = targets[i];
+    s += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (part[0] + part[1] + part[2] + part[3]) / (float)count;
+}
+
+template <typename F>
+hipError_t ln_dispatch(int H, F&& f) {
+  switch (H) {
+    case 128: return f.template operator()<2, 1>();
+    case 256: return f.template operator()<4, 1>();
+    case 384: return f.template operator()<2, 3>();
+    case 512: return f.template operator()<4, 2>();
+    case 768: return f.template operator()<4, 3>();
+    case 1024: return f.template operator()<4, 4>();
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                            bf16_t* out, int T, int H, hipStream_t st) {
+  if (T <= 0) return hipSuccess;
+  return ln_dispatch(H, [&]<int VEC, int NIT>() {
+    hipLaunchKernelGGL((layernorm_kernel<VEC, NIT>), dim3((T + 3) / 4), dim3(256), 0, st, x, gamma,
+                       beta, eps, out, T, H);
+    return hipGetLastError();
+  });
+}
+
+hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
+                           const float* word, const float* pos, const float* type,
+                           const float* gamma, const float* beta, float eps, bf16_t* out, int T,
+                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st) {
+  if (T <= 0) return hipSuccess;
+  return ln_dispatch(H, [&]<int VEC, int NIT>() {
+    hipLaunchKernelGGL((embed_ln_kernel<VEC, NIT>), dim3((T + 3) / 4), dim3(256), 0, st, ids,
+                       type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H, vocab,
+                       max_pos, type_vocab);
+    return hipGetLastError();
+  });
+}
+
+hipError_t launch_gather_rows(const bf16_t* src, const int32_t* rows, bf16_t* dst, int n, int H,
+                              hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, src, rows, dst, n, H);
+  return hipGetLastError();
+}
+
+hipError_t launch_classifier(const bf16_t* x, const int32_t* rows, const float* Wc,
+                             const float* bc, float* logits, int n, int H, int L, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (L > 8 || H % 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(classifier_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, rows, Wc, bc,
+                     logits, n, H, L);
+  return hipGetLastError();
+}
+
+hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
+                              int sep_id, int n_ctx, int32_t* focus, int32_t* err,
+                              hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(focus_index_kernel, dim3(n_seqs), dim3(64), 0, st, ids, cu_seqlens, n_seqs,
+                     sep_id, n_ctx, focus, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_epilogue(const float* logits, const double* label_thresh, float any_thresh,
+                           int n, int L, float* probs, float* max_score, uint8_t* labels,
+                           uint8_t* keep, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (L > 8 || L < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(epilogue_kernel, dim3((n + 31) / 32), dim3(256), 0, st, logits, label_thresh,
+                     any_thresh, n, L, probs, max_score, labels, keep);
+  return hipGetLastError();
+}
+
+hipError_t launch_bce_loss(const float* logits, const float* targets, int count, float* loss,
+                           hipStream_t st) {
+  if (count <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bce_loss_kernel, dim3(1), dim3(256), 0, st, logits, targets, count, loss);
+  return hipGetLastError();
+}

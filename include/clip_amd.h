@@ -1,0 +1,123 @@
+/* clip_amd.h — C ABI of libclip_amd.so, the MI355X (gfx950) engine for the bulk BERT(+Context)
+ * sentence-scoring path of asappresearch/clip.
+ *
+ * The reference has no FFI/plugin layer on this path: the boundary it sits behind is the Python
+ * nn.Module contract (from_pretrained / load_state_dict / set_* / forward -> (loss, logits)) plus
+ * the inline numpy epilogue of the driver.  Each entry point below cites the reference lines whose
+ * work it takes over; clip_amd/bert_model.py and clip_amd/scoring.py are the host mirrors that
+ * bind these symbols with ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (CLIP_OK) or a negative
+ * clip_status; no C++ exception crosses the ABI; clip_last_error() gives the message of the last
+ * failure on the calling thread.  Pointers named dev_* are device (HIP) pointers owned by the
+ * caller (e.g. torch tensors' data_ptr()), host_* are host pointers.  `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  One engine per device per process; an engine is not
+ * re-entrant (its workspace is shared by all calls on it).
+ */
+#ifndef CLIP_AMD_H
+#define CLIP_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum clip_status {
+  CLIP_OK = 0,
+  CLIP_ERR_ARG = -1,       /* bad argument (null pointer, unsupported shape, unknown name) */
+  CLIP_ERR_HIP = -2,       /* a HIP runtime call failed */
+  CLIP_ERR_STATE = -3,     /* call order: weights missing / not finalized */
+  CLIP_ERR_CAPACITY = -4,  /* n_seqs / total_tokens beyond the engine's workspace */
+  CLIP_ERR_SEP_COUNT = -5  /* a row does not hold exactly 2n+1 [SEP] (bert_model.py:51-55) */
+} clip_status;
+
+typedef struct clip_engine clip_engine; /* opaque */
+
+/* Encoder geometry = the transformers.BertConfig fields the reference reads
+ * (sentclf/apply_bert_unlabeled.py:55-62; sentclf/bert_model.py:13-19). */
+typedef struct clip_config {
+  int32_t vocab_size, hidden_size, num_layers, num_heads, intermediate_size;
+  int32_t max_position, type_vocab_size, num_labels;
+  float layer_norm_eps;
+  int32_t max_tokens; /* workspace capacity: packed tokens per forward call */
+  int32_t max_seqs;   /* workspace capacity: sequences per forward call */
+} clip_config;
+
+/* Replaces model construction + model.to(device) (apply_bert_unlabeled.py:65-72; test_load.py:21).
+ * Allocates device weights and the activation workspace on `device_id`. */
+int clip_create(const clip_config* cfg, int device_id, clip_engine** out);
+int clip_destroy(clip_engine* e);
+
+/* Replaces model.load_state_dict(sd) (apply_bert_unlabeled.py:78-79), one tensor per call, using
+ * the reference's 201 state-dict key names; host_data is fp32, row-major, `numel`
+ * elements.  "bert.embeddings.position_ids" and other unknown buffers return CLIP_ERR_ARG and may
+ * be skipped by the caller.  clip_finalize_weights() fails with CLIP_ERR_STATE if a key is missing;
+ * it builds the fused bf16 QKV weight (1/sqrt(head_dim) folded into the query rows). */
+int clip_load_weight(clip_engine* e, const char* name, const float* host_data, int64_t numel);
+int clip_finalize_weights(clip_engine* e);
+
+/* Replaces _collect_focus_repr's index search (bert_model.py:52): for each packed sequence the
+ * token index of its (n_ctx+1)-th `sep_id`; n_ctx < 0 selects the first token ([CLS], the pooler
+ * row of bert_model.py:234).  dev_err[0] gets bit 0 set when a sequence does not hold exactly
+ * 2*n_ctx+1 separators. */
+int clip_focus_index(const int32_t* dev_ids, const int32_t* dev_cu_seqlens, int32_t n_seqs,
+                     int32_t sep_id, int32_t n_ctx, int32_t* dev_focus, int32_t* dev_err,
+                     void* stream);
+
+/* Replaces model(**inputs) (apply_bert_unlabeled.py:110; test_load.py:36; bert_model.py:66-103
+ * and :210-251) on PACKED rows: token t of sequence s sits at dev_ids[cu_seqlens[s] + t]; the
+ * key-padding mask of the reference (modeling_bert.py:688-708) is replaced by the packing.
+ *   head_kind 0: hidden state at dev_focus[s] -> classifier           (context model)
+ *   head_kind 1: tanh pooler on dev_focus[s] (= [CLS]) -> classifier  (sentence-only model)
+ * dev_type_ids may be NULL (all zero).  dev_logits is fp32 [n_seqs, num_labels]. */
+int clip_forward_packed(clip_engine* e, const int32_t* dev_ids, const int32_t* dev_type_ids,
+                        const int32_t* dev_pos_ids, const int32_t* dev_cu_seqlens,
+                        const int32_t* dev_focus, int32_t n_seqs, int32_t total_tokens,
+                        int32_t max_seqlen, int32_t head_kind, float* dev_logits, void* stream);
+
+/* Replaces the numpy epilogue of the driver (apply_bert_unlabeled.py:111-124) and the per-label
+ * decision of test_load.py:37-38: probs = sigmoid(logits) (fp32); labels[i,j] = (double)p > t_j
+ * (strict, fp64 thresholds); keep[i] = any_j(p > any_thresh) (fp32 compare, as numpy does for a
+ * float32 array against a Python float); max_score[i] = max_j p.  Any output pointer may be NULL;
+ * dev_label_thresh may be NULL when dev_labels is NULL. */
+int clip_epilogue(const float* dev_logits, const double* dev_label_thresh, float any_thresh,
+                  int32_t n, int32_t num_labels, float* dev_probs, float* dev_max_score,
+                  uint8_t* dev_labels, uint8_t* dev_keep, void* stream);
+
+/* Replaces F.binary_cross_entropy_with_logits(logits, labels) (bert_model.py:97): mean over all
+ * `count` elements, written to dev_loss[0]. */
+int clip_bce_loss(const float* dev_logits, const float* dev_targets, int32_t count,
+                  float* dev_loss, void* stream);
+
+/* ---- single-kernel entry points (parity tests drive each kernel through the ABI) ---- */
+/* out[M,N] = epi(A[M,K] W[N,K]^T + bias): epi 0 bias, 1 bias+erf-GELU, 2 bias+residual, 3 bias+tanh
+ * (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463). A, W, res are bf16; out bf16 or
+ * fp32 (out_f32). Leading dimensions in elements. */
+int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                   const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
+                   int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
+                   int32_t out_f32, void* stream);
+/* softmax(q k^T) v per packed sequence and head (modeling_bert.py:111-136), q pre-scaled;
+ * qkv bf16 [T, 3*hidden], ctx bf16 [T, hidden], head_dim 64. */
+int clip_attention_varlen(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens,
+                          uint16_t* dev_ctx, int32_t n_seqs, int32_t max_seqlen, int32_t n_heads,
+                          int32_t hidden, void* stream);
+/* out_bf16[t] = LayerNorm(x_f32[t]) (modeling_bert.py:292,350) */
+int clip_layernorm(const float* dev_x, const float* dev_gamma, const float* dev_beta, float eps,
+                   uint16_t* dev_out, int32_t T, int32_t H, void* stream);
+/* BertEmbeddings.forward (modeling_bert.py:68-108): tables fp32, out bf16 [T,H] */
+int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
+                         const int32_t* dev_pos_ids, const float* dev_word, const float* dev_pos,
+                         const float* dev_type, const float* dev_gamma, const float* dev_beta,
+                         float eps, uint16_t* dev_out, int32_t T, int32_t H, int32_t vocab,
+                         int32_t max_pos, int32_t type_vocab, void* stream);
+
+/* message of the last failing call on this thread ("" if none) */
+const char* clip_last_error(void);
+/* ABI version of this header */
+int clip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIP_AMD_H */

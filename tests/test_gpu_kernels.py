@@ -1,0 +1,225 @@
+"""Per-kernel parity on a real MI355X, every call through the C ABI (include/clip_amd.h).
+Floating-point kernels are compared with a plain PyTorch fp32 reference of the same op computed
+from the SAME bf16-rounded inputs; tolerances are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clip_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return _lib.load()
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _gemm(lib, A, W, bias, res, epi, out_f32):
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+    _lib.check(lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out),
+                                  M, N, K, A.stride(0), W.stride(0), out.stride(0),
+                                  0 if res is None else res.stride(0), epi, int(out_f32), _lib.stream_ptr()))
+    _sync()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,epi,out_f32", [
+    (128, 128, 64, 0, True),          # one tile, one K step
+    (300, 384, 128, 0, False),        # M and N tails
+    (1024, 768, 768, 2, True),        # attention-output projection + residual
+    (515, 2304, 768, 0, False),       # fused QKV
+    (257, 3072, 768, 1, False),       # FFN up + erf-GELU
+    (640, 768, 3072, 2, True),        # FFN down + residual
+    (48, 768, 768, 3, False),         # pooler tanh, M < tile
+    (1, 128, 128, 0, True),
+])
+def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + epi)
+    A = (torch.randn(M, K, generator=g) * 1.0).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    # asymmetric structure so a transposed write cannot pass
+    W[:, 0] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.01
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
+    out = _gemm(lib, A, W, bias, res, epi, out_f32).float()
+    ref = A.float() @ W.float().T + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = ref + res.float()
+    elif epi == 3:
+        ref = torch.tanh(ref)
+    # fp32 accumulation in a different order: 1e-3 abs on O(1..30) values for f32 out;
+    # bf16 out adds one rounding: 2^-8 relative
+    tol = 2e-3 + (0 if out_f32 else 4e-3 * ref.abs().max().item())
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < tol
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    A = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(16, device="cuda")
+    o = torch.zeros(16, 16, device="cuda")
+    rc = lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), None, _lib.ptr(o), 16, 16, 100, 100, 100, 16, 0, 0, 1, None)
+    assert rc == _lib.CLIP_ERR_ARG and b"multiple of 64" in lib.clip_last_error()
+
+
+def _attn_ref(qkv, lens, heads):
+    T, H3 = qkv.shape
+    H = H3 // 3
+    out = torch.zeros(T, H, dtype=torch.float32, device=qkv.device)
+    off = 0
+    x = qkv.float()
+    for L in lens:
+        q, k, v = (x[off:off + L, i * H:(i + 1) * H].view(L, heads, 64).transpose(0, 1) for i in range(3))
+        p = torch.softmax(q @ k.transpose(1, 2), dim=-1)          # q is pre-scaled
+        out[off:off + L] = (p @ v).transpose(0, 1).reshape(L, H)
+        off += L
+    return out
+
+
+@pytest.mark.parametrize("lens,heads", [
+    ([1, 5, 31, 32, 33, 64, 65, 127, 128, 129, 200, 256, 300, 512], 2),
+    ([256] * 6, 12),
+    ([7, 19, 23], 12),
+])
+def test_attention_matches_fp32_reference(lib, lens, heads):
+    H = heads * 64
+    T = sum(lens)
+    g = torch.Generator(device="cpu").manual_seed(T + heads)
+    qkv = torch.randn(T, 3 * H, generator=g)
+    qkv[:, :H] *= 0.4                 # scores with a spread of a few units
+    qkv = qkv.to(torch.bfloat16).cuda()
+    cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32, device="cuda")
+    ctx = torch.full((T, H), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.clip_attention_varlen(_lib.ptr(qkv), _lib.ptr(cu), _lib.ptr(ctx), len(lens), max(lens),
+                                         heads, H, _lib.stream_ptr()))
+    _sync()
+    ref = _attn_ref(qkv, lens, heads)
+    assert torch.isfinite(ctx.float()).all()
+    # P is rounded to bf16 before P.V and the output is bf16: 2e-2 abs on |out| <~ 3
+    err = (ctx.float() - ref).abs().max().item()
+    assert err < 2e-2, err
+
+
+def test_attention_online_softmax_rescale(lib):
+    """Force the running max to jump at a later key tile (guide rule 26)."""
+    heads, H, L = 1, 64, 200
+    qkv = torch.zeros(L, 3 * H)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    qkv[:, :H] = torch.randn(L, H, generator=g) * 0.3
+    qkv[:, H:2 * H] = torch.randn(L, H, generator=g) * 0.3
+    qkv[:, 2 * H:] = torch.randn(L, H, generator=g)
+    qkv[150, H:2 * H] = qkv[10, :H] * 40.0        # key 150 (tile 2) spikes against query 10
+    qkv = qkv.to(torch.bfloat16).cuda()
+    cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    ctx = torch.empty((L, H), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.clip_attention_varlen(_lib.ptr(qkv), _lib.ptr(cu), _lib.ptr(ctx), 1, L, heads, H, _lib.stream_ptr()))
+    _sync()
+    ref = _attn_ref(qkv, [L], heads)
+    assert (ctx.float() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("T,H", [(1, 768), (1000, 768), (37, 128), (64, 1024)])
+def test_layernorm(lib, T, H):
+    g = torch.Generator(device="cpu").manual_seed(T + H)
+    x = (torch.randn(T, H, generator=g) * 3 + 1).cuda()
+    gamma, beta = torch.randn(H, generator=g).cuda(), torch.randn(H, generator=g).cuda()
+    out = torch.empty(T, H, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.clip_layernorm(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(out), T, H, _lib.stream_ptr()))
+    _sync()
+    ref = torch.nn.functional.layer_norm(x, (H,), gamma, beta, 1e-12)
+    # output rounded to bf16: 2^-8 relative (+1e-5 abs)
+    assert ((out.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5).all()
+
+
+def test_embed_layernorm(lib):
+    T, H, V, P, TY = 777, 768, 5000, 512, 2
+    g = torch.Generator(device="cpu").manual_seed(5)
+    word, pos, typ = (torch.randn(n, H, generator=g).cuda() for n in (V, P, TY))
+    gamma, beta = torch.randn(H, generator=g).cuda(), torch.randn(H, generator=g).cuda()
+    ids = torch.randint(0, V, (T,), generator=g, dtype=torch.int32).cuda()
+    tt = torch.randint(0, TY, (T,), generator=g, dtype=torch.int32).cuda()
+    po = torch.randint(0, P, (T,), generator=g, dtype=torch.int32).cuda()
+    out = torch.empty(T, H, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.clip_embed_layernorm(_lib.ptr(ids), _lib.ptr(tt), _lib.ptr(po), _lib.ptr(word), _lib.ptr(pos),
+                                        _lib.ptr(typ), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(out),
+                                        T, H, V, P, TY, _lib.stream_ptr()))
+    _sync()
+    ref = torch.nn.functional.layer_norm(word[ids.long()] + typ[tt.long()] + pos[po.long()], (H,), gamma, beta, 1e-12)
+    assert ((out.float() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5).all()
+
+
+def test_focus_index(lib):
+    rows = [[101, 5, 102, 102, 7, 8, 102, 9, 102, 102],          # focus sep = index 6
+            [101] + [9] * 70 + [102, 102] + [4] * 100 + [102, 3, 102, 102],  # beyond one 64-token sweep
+            [101, 102, 102, 5, 102, 102, 102]]
+    ids = torch.tensor(sum(rows, []), dtype=torch.int32, device="cuda")
+    lens = [len(r) for r in rows]
+    cu = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32, device="cuda")
+    focus = torch.empty(3, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.clip_focus_index(_lib.ptr(ids), _lib.ptr(cu), 3, 102, 2, _lib.ptr(focus), _lib.ptr(err), None))
+    _sync()
+    exp = []
+    for r, o in zip(rows, cu.tolist()):
+        exp.append(o + [i for i, t in enumerate(r) if t == 102][2])
+    assert focus.tolist() == exp and err.item() == 0
+    # wrong [SEP] count is flagged (bert_model.py:51-55)
+    _lib.check(lib.clip_focus_index(_lib.ptr(ids), _lib.ptr(cu), 3, 102, 1, _lib.ptr(focus), _lib.ptr(err), None))
+    _sync()
+    assert err.item() == 1
+    # [CLS] row for the sentence-only head
+    _lib.check(lib.clip_focus_index(_lib.ptr(ids), _lib.ptr(cu), 3, 0, -1, _lib.ptr(focus), _lib.ptr(err), None))
+    _sync()
+    assert focus.tolist() == cu.tolist()[:3]
+
+
+def test_epilogue_bit_exact_decisions(lib):
+    from oracle import bert_oracle as O
+    g = torch.Generator(device="cpu").manual_seed(9)
+    n = 10007
+    logits = torch.randn(n, 7, generator=g) * 2
+    t32 = np.float32(0.05)
+    logits[0] = float(np.log(t32 / (1 - t32)))            # sits on the any-threshold
+    logits[1] = -20.0
+    thr = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
+    d_logits, d_thr = logits.cuda(), torch.tensor(thr, dtype=torch.float64, device="cuda")
+    probs = torch.empty(n, 7, device="cuda")
+    mx = torch.empty(n, device="cuda")
+    labels = torch.empty(n, 7, dtype=torch.uint8, device="cuda")
+    keep = torch.empty(n, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.clip_epilogue(_lib.ptr(d_logits), _lib.ptr(d_thr), 0.05, n, 7, _lib.ptr(probs), _lib.ptr(mx),
+                                 _lib.ptr(labels), _lib.ptr(keep), None))
+    _sync()
+    p_ref, keep_ref, score_ref = O.score_epilogue(logits, 0.05)
+    p = probs.cpu().numpy()
+    # sigmoid: within 2 ulp of torch's CPU fp32 sigmoid
+    assert np.abs(p - p_ref).max() <= 2 * np.finfo(np.float32).eps
+    # decisions are bit-exact functions of the device's own fp32 probabilities
+    assert (labels.cpu().numpy().astype(bool) == O.label_decisions(p, thr)).all()
+    assert (keep.cpu().numpy().astype(bool) == np.any(p > np.float32(0.05), axis=1)).all()
+    assert (mx.cpu().numpy() == p.max(axis=1)).all()
+    # and agree with the oracle's end-to-end decisions except where a probability is within 2 ulp of a threshold
+    agree = (labels.cpu().numpy().astype(bool) == O.label_decisions(p_ref, thr)).mean()
+    assert agree > 0.9999
+
+
+def test_bce_loss(lib):
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = (torch.randn(8, 7, generator=g) * 3).cuda()
+    y = (torch.rand(8, 7, generator=g) < 0.3).float().cuda()
+    loss = torch.empty(1, device="cuda")
+    _lib.check(lib.clip_bce_loss(_lib.ptr(x), _lib.ptr(y), 56, _lib.ptr(loss), None))
+    _sync()
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x, y)
+    assert abs(loss.item() - ref.item()) < 1e-6

@@ -1,0 +1,101 @@
+"""End-to-end parity of the HIP engine against the reference's own outputs (tests/golden/*.npz),
+through the host mirror of the reference's model API (clip_amd/bert_model.py -> C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clip_amd.bert_model import args_to_model  # noqa: E402
+from clip_amd.weights import procedural_state_dict  # noqa: E402
+from oracle import bert_oracle as O  # noqa: E402  (checker only)
+
+DNOTE = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])   # clip_dnote_label_threshs.npy
+TTP = np.array([0.18, 0.6, 0.11, 0.32, 0.1, 0.1, 0.18])                        # clip_ttp_label_threshs.npy
+BF16_LOGIT_TOL = 2e-2   # BASELINE.json north_star: per-label logits within 2e-2 abs in bf16
+
+
+def build_model(g):
+    model = args_to_model(g["n_ctx"])(g["cfg"], max_tokens=16384, max_seqs=256)
+    model.load_state_dict(procedural_state_dict(g["cfg"], g["seed"]))
+    model.to("cuda").eval()
+    if g["n_ctx"] > 0:
+        model.set_sep_token_id(102)
+        model.set_n_context_sentences(g["n_ctx"])
+    model.set_task("multilabel")
+    return model
+
+
+def run_padded(model, g):
+    """the reference's loop: DataLoader(batch_size, shuffle=False), pad to longest, forward"""
+    logits, losses = [], []
+    bs = g["batch_size"]
+    for i in range(0, len(g["rows"]), bs):
+        ids, mask = O.pad_batch(g["rows"][i:i + bs])
+        inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda(),
+                  "labels": torch.from_numpy(g["labels"][i:i + bs]).cuda()}
+        if g["n_ctx"] > 0:
+            inputs["token_type_ids"] = O.token_type_ids_from_seps(ids, 102, g["n_ctx"]).cuda()
+        loss, pred = model(**inputs)
+        logits.append(pred.cpu().numpy())
+        losses.append(float(loss))
+    return np.concatenate(logits), np.asarray(losses)
+
+
+@pytest.mark.parametrize("name", ["tiny_ctx", "tiny_ctx_n1", "tiny_sent", "base_ctx", "base_sent"])
+def test_forward_matches_reference(golden, name):
+    g = golden(name)
+    model = build_model(g)
+    logits, losses = run_padded(model, g)
+    err = np.abs(logits - g["ref_logits"]).max()
+    print(f"{name}: max |logit - ref| = {err:.3e}")
+    assert np.isfinite(logits).all()
+    assert err < BF16_LOGIT_TOL
+    assert np.abs(losses - g["ref_batch_loss"]).max() < 5e-3
+    # thresholded labels: every decision whose reference probability is not within 5e-3 of its
+    # threshold must agree (the >= 99.9 % agreement target is measured at scale in bench/scoring tests)
+    p = 1 / (1 + np.exp(-logits.astype(np.float64)))
+    for thr in (DNOTE, TTP):
+        ref_dec = O.label_decisions(g["ref_probs"], thr)
+        dec = O.label_decisions(p.astype(np.float32), thr)
+        clear = np.abs(g["ref_probs"] - thr) > 5e-3
+        assert (dec == ref_dec)[clear].all()
+
+
+def test_packed_path_equals_padded_path(golden):
+    """All rows in ONE packed call (the scoring driver's path) vs batches of 8 padded rows."""
+    g = golden("base_ctx")
+    model = build_model(g)
+    padded, _ = run_padded(model, g)
+    rows = g["rows"]
+    lens = np.asarray([len(r) for r in rows])
+    ids = torch.from_numpy(np.concatenate(rows).astype(np.int32)).cuda()
+    cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
+    pos = torch.from_numpy(np.concatenate([np.arange(n) for n in lens]).astype(np.int32)).cuda()
+    ids2d, _ = O.pad_batch(rows)
+    tt2d = O.token_type_ids_from_seps(ids2d, 102, 2)
+    tt = torch.cat([tt2d[i, :n] for i, n in enumerate(lens)]).to(torch.int32).cuda()
+    logits = model.forward_packed(ids, tt, pos, cu, int(lens.max())).cpu().numpy()
+    # same kernels, same per-row arithmetic: batching must not change a row's result at all
+    assert np.array_equal(logits, padded)
+    assert np.abs(logits - g["ref_logits"]).max() < BF16_LOGIT_TOL
+
+
+def test_wrong_sep_count_raises_like_the_reference(golden):
+    g = golden("tiny_ctx")
+    model = build_model(g)
+    ids = torch.tensor([[101, 5, 102, 6, 102, 7, 102, 0]], device="cuda")       # 3 seps, needs 5
+    mask = (ids != 0).long()
+    with pytest.raises(TypeError):
+        model(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids),
+              labels=torch.zeros(1, 7, device="cuda"))
+
+
+def test_no_cpu_path(golden):
+    g = golden("tiny_ctx")
+    model = args_to_model(2)(g["cfg"])
+    model.load_state_dict(procedural_state_dict(g["cfg"], g["seed"]))
+    model.set_sep_token_id(102); model.set_n_context_sentences(2)
+    ids = torch.tensor([[101, 102, 102, 5, 102, 102, 102]])
+    with pytest.raises(RuntimeError):
+        model(input_ids=ids)
