@@ -1,0 +1,183 @@
+"""bench.py — sentences/sec of the bulk BERT-base+Context scoring path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one resident batch of synthetic context-packed rows
+(config 3 of BASELINE.json, fixed-length variant: every row has exactly --seq-len tokens):
+focus-[SEP] index -> 12-layer encoder -> classifier -> fused sigmoid/threshold/max epilogue.
+Inputs are already in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from clip_amd import _lib, synth  # noqa: E402
+from clip_amd.bert_model import BertSequenceMultilabelClassificationContext  # noqa: E402
+from clip_amd.config import BertConfig  # noqa: E402
+from clip_amd.weights import procedural_state_dict  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+DNOTE_THRESHS = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
+
+
+def flops_per_row(L, cfg):
+    """F(L) = layers*[2L(4H^2 + 2HI) + 4L^2 H] + 2*H*labels (real tokens only)."""
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    return cfg.num_hidden_layers * (2 * L * (4 * H * H + 2 * H * I) + 4 * L * L * H) + 2 * H * cfg.num_labels
+
+
+def make_batch(rows, n_ctx, device):
+    lens = np.asarray([len(r) for r in rows], np.int32)
+    ids = np.concatenate(rows).astype(np.int32)
+    cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+    # token types of sentclf/bert.py:168-176 on packed rows
+    tt = np.zeros_like(ids)
+    for s, (b, e) in enumerate(zip(cu[:-1], cu[1:])):
+        sep = np.nonzero(ids[b:e] == 102)[0]
+        tt[b:b + sep[n_ctx - 1]] = 1
+        tt[b + sep[n_ctx]:e] = 1
+    t = lambda a: torch.from_numpy(a).to(device)
+    return {"ids": t(ids), "tt": t(tt), "pos": t(pos), "cu": t(cu), "max_len": int(lens.max()),
+            "n": len(rows), "tokens": int(lens.sum()), "lens": lens}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows-per-step", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = BertConfig()
+    n_ctx = 2
+    sd = procedural_state_dict(cfg, 0)
+    tokens = args.rows_per_step * args.seq_len
+    model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=tokens, max_seqs=args.rows_per_step)
+    model.load_state_dict(sd)
+    model.to(device).eval()
+    model.set_sep_token_id(102)
+    model.set_n_context_sentences(n_ctx)
+    model.set_task("multilabel")
+    lib = _lib.load()
+    engine = model._ensure_engine()
+
+    # two resident batches per rank (documents are sharded by rank: different seeds = different rows)
+    all_rows = synth.context_rows(2 * args.rows_per_step, n_ctx, cfg.vocab_size, seed=1002 + 17 * rank,
+                                  fixed_len=args.seq_len)
+    batches = [make_batch(all_rows[i * args.rows_per_step:(i + 1) * args.rows_per_step], n_ctx, device)
+               for i in range(2)]
+    thr = torch.tensor(DNOTE_THRESHS, dtype=torch.float64, device=device)
+    n = args.rows_per_step
+    out = {"max": torch.empty(n, device=device), "keep": torch.empty(n, dtype=torch.uint8, device=device),
+           "labels": torch.empty((n, cfg.num_labels), dtype=torch.uint8, device=device)}
+    stream = _lib.stream_ptr()
+
+    def step(b):
+        logits = model.forward_packed(b["ids"], b["tt"], b["pos"], b["cu"], b["max_len"], check=False)
+        _lib.check(lib.clip_epilogue(_lib.ptr(logits), _lib.ptr(thr), 0.05, b["n"], cfg.num_labels, None,
+                                     _lib.ptr(out["max"]), _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), stream))
+        return logits
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % 2])
+    barrier()
+    dominant = _lib.KINDS.index("gemm_ffn_up")
+    mask = (1 << len(_lib.KINDS)) - 1 if args.breakdown else (1 << dominant)
+    _lib.check(lib.clip_profile_enable(engine, mask))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[i % 2])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * len(_lib.KINDS))()
+    cnt = (C.c_int64 * len(_lib.KINDS))()
+    _lib.check(lib.clip_profile_read(engine, ms, cnt, 1))
+    _lib.check(lib.clip_profile_enable(engine, 0))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        rows_total = world * args.rows_per_step * args.steps
+        value = rows_total / elapsed
+        T = batches[0]["tokens"]
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        gemm_flops = 2.0 * T * H * I                       # FFN-up GEMM, one launch
+        avg_ms = ms[dominant] / max(cnt[dominant], 1)
+        achieved = gemm_flops / (avg_ms * 1e-3) / 1e12
+        model_flops = sum(flops_per_row(int(L), cfg) for L in batches[0]["lens"])
+        res = {
+            "metric": "sentences/sec scored (whole node) BERT-base+Context seq256 bf16",
+            "value": round(value, 2), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic token ids (uniform in [1000, vocab)), procedural N(0,0.02) weights",
+            "config": {"workload": f"C3 BERT-base+Context n_ctx=2, fixed L={args.seq_len}, "
+                                   f"{args.rows_per_step} rows ({T} tokens) per step per GPU",
+                       "rows_per_step": args.rows_per_step, "seq_len": args.seq_len,
+                       "sharding": f"documents over {world} rank(s), no collective while scoring"},
+            "model_tflops_per_gpu": round(model_flops * args.steps / elapsed / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_BIAS_GELU> (FFN up, M=%d N=%d K=%d)" % (T, I, H),
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
+                         "flops_per_launch": gemm_flops},
+        }
+        if args.breakdown:
+            res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import bert_oracle as O    # CPU baseline leg only
+            sample = all_rows[:64]
+            t1 = time.perf_counter()
+            _, keep_ref, score_ref, logits_ref = O.score_rows(sd, cfg, sample, n_ctx, batch_size=8)
+            dt = time.perf_counter() - t1
+            res["cpu_baseline"] = {
+                "value": round(len(sample) / dt, 3), "unit": "sentences/s", "cores": torch.get_num_threads(),
+                "kind": "port", "sample": f"first {len(sample)} rows of the same workload, batch 8 padded "
+                f"(apply_bert_unlabeled.py:92 semantics), torch {torch.__version__} fp32 CPU oracle, {dt:.1f} s"}
+            # the same rows through the GPU path, as a live parity check beside the numbers
+            g = model.forward_packed(batches[0]["ids"], batches[0]["tt"], batches[0]["pos"], batches[0]["cu"],
+                                     batches[0]["max_len"]).cpu().numpy()[:len(sample)]
+            res["parity_vs_cpu_oracle_max_abs_logit"] = float(np.abs(g - logits_ref).max())
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,12 @@ struct clip_engine {
   bf16_t *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
          *pooled = nullptr;
   float* preln = nullptr;
+  // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
+  uint32_t prof_mask = 0;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int kind; hipEvent_t a, b; };
+  std::vector<Span> spans;
 };
 
 namespace {
@@ -106,6 +112,29 @@ const std::vector<float>* find(clip_engine* e, const std::string& k, size_t nume
 
 }  // namespace
 
+namespace {
+struct ProfScope {
+  clip_engine* e; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ProfScope(clip_engine* e_, int kind_, hipStream_t st_) : e(e_), kind(kind_), st(st_) {
+    on = (e->prof_mask >> kind) & 1u;
+    if (!on) return;
+    while (e->ev_pool.size() < e->ev_used + 2) {
+      hipEvent_t ev;
+      if (hipEventCreate(&ev) != hipSuccess) { on = false; return; }
+      e->ev_pool.push_back(ev);
+    }
+    a = e->ev_pool[e->ev_used++];
+    b = e->ev_pool[e->ev_used++];
+    (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, st);
+    e->spans.push_back({kind, a, b});
+  }
+};
+}  // namespace
+
 extern "C" {
 
 const char* clip_last_error(void) { return g_err.c_str(); }
@@ -147,8 +176,9 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
 
 int clip_destroy(clip_engine* e) {
   if (!e) return CLIP_OK;
-  hipSetDevice(e->device);
-  for (void* p : e->allocs) hipFree(p);
+  (void)hipSetDevice(e->device);
+  for (void* p : e->allocs) (void)hipFree(p);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   delete e;
   return CLIP_OK;
 }
@@ -275,24 +305,49 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   const clip_config& c = e->cfg;
   const int H = c.hidden_size, I = c.intermediate_size;
 
-  HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
-                          c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
-                          c.type_vocab_size, st));
+  {
+    ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
+    HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
+                            c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
+                            c.type_vocab_size, st));
+  }
   GemmArgs g;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
-    g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
-    HIP_TRY(launch_gemm(g, st));
-    HIP_TRY(launch_attention(e->qkv, cu, e->ctx, n_seqs, max_seqlen, c.num_heads, H, st));
-    g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, T, H, H, H, H, H, H, EPI_BIAS_RES, true};
-    HIP_TRY(launch_gemm(g, st));
-    HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st));
-    g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, T, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
-    HIP_TRY(launch_gemm(g, st));
-    g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, T, H, I, I, I, H, H, EPI_BIAS_RES, true};
-    HIP_TRY(launch_gemm(g, st));
-    HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st));
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
+      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_ATTENTION, st);
+      HIP_TRY(launch_attention(e->qkv, cu, e->ctx, n_seqs, max_seqlen, c.num_heads, H, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
+      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, T, H, H, H, H, H, H, EPI_BIAS_RES, true};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+      HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
+      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, T, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
+      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, T, H, I, I, I, H, H, EPI_BIAS_RES, true};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+      HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st));
+    }
   }
+  ProfScope ps_head(e, CLIP_KIND_HEAD, st);
   if (head_kind == 0) {
     HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
   } else {
@@ -303,6 +358,26 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
                               c.num_labels, st));
   }
+  return CLIP_OK;
+}
+
+int clip_profile_enable(clip_engine* e, uint32_t kind_mask) {
+  if (!e) return fail(CLIP_ERR_ARG, "clip_profile_enable: null engine");
+  e->prof_mask = kind_mask & ((1u << CLIP_N_KINDS) - 1);
+  return CLIP_OK;
+}
+
+int clip_profile_read(clip_engine* e, double* ms, int64_t* launches, int32_t reset) {
+  if (!e || !ms || !launches) return fail(CLIP_ERR_ARG, "clip_profile_read: null argument");
+  for (int k = 0; k < CLIP_N_KINDS; ++k) { ms[k] = 0.0; launches[k] = 0; }
+  for (const auto& s : e->spans) {
+    HIP_TRY(hipEventSynchronize(s.b));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, s.a, s.b));
+    ms[s.kind] += t;
+    launches[s.kind] += 1;
+  }
+  if (reset) { e->spans.clear(); e->ev_used = 0; }
   return CLIP_OK;
 }
 

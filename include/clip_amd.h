@@ -112,6 +112,19 @@ int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
                          float eps, uint16_t* dev_out, int32_t T, int32_t H, int32_t vocab,
                          int32_t max_pos, int32_t type_vocab, void* stream);
 
+/* HIP-event timing of the kernels inside clip_forward_packed, for bench.py's roofline figure (no
+ * counterpart in the reference, which has no profiling: SURVEY.md 5).  Bit k of kind_mask turns
+ * kind k on; events are recorded on the forward's stream around each launch of that kind.
+ * clip_profile_read() waits for the recorded events and returns summed milliseconds and launch
+ * counts per kind (arrays of CLIP_N_KINDS). */
+enum {
+  CLIP_KIND_EMBED_LN = 0, CLIP_KIND_GEMM_QKV = 1, CLIP_KIND_ATTENTION = 2,
+  CLIP_KIND_GEMM_ATTN_OUT = 3, CLIP_KIND_LAYERNORM = 4, CLIP_KIND_GEMM_FFN_UP = 5,
+  CLIP_KIND_GEMM_FFN_DOWN = 6, CLIP_KIND_HEAD = 7, CLIP_N_KINDS = 8
+};
+int clip_profile_enable(clip_engine* e, uint32_t kind_mask);
+int clip_profile_read(clip_engine* e, double* ms_per_kind, int64_t* launches_per_kind, int32_t reset);
+
 /* message of the last failing call on this thread ("" if none) */
 const char* clip_last_error(void);
 /* ABI version of this header */
