@@ -399,8 +399,9 @@ int clip_bce_loss(const float* logits, const float* targets, int32_t count, floa
 
 int clip_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res,
                    void* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
-                   int32_t ldo, int32_t ldres, int32_t epi, int32_t out_f32, void* stream) {
-  GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, out_f32 != 0};
+                   int32_t ldo, int32_t ldres, int32_t epi, int32_t out_f32, int32_t tile,
+                   void* stream) {
+  GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, out_f32 != 0, tile};
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   HIP_TRY(launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;

@@ -1,13 +1,19 @@
 // bf16 MFMA GEMM for the encoder projections:  out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N])
 //   A = activations (row-major, K contiguous), W = nn.Linear weight [out,in] (K contiguous).
 // Restates the dense layers of transformers BertSelfAttention/BertSelfOutput/BertIntermediate/
-// BertOutput (modeling_bert.py:175-177, 289-293, 334-337, 347-351) that the reference's
-// sentclf/bert_model.py:79-88 runs; the epilogues fuse bias, erf-GELU, residual add and tanh.
+// BertOutput/BertPooler (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463) that the
+// reference's sentclf/bert_model.py:79-88 runs; the epilogues fuse bias, erf-GELU, residual add,
+// tanh.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2, 64x64 each, 16x16x32 MFMA).
-// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop), double-buffered,
-// one barrier per K tile.  LDS rows are 128 B; 16-B chunks are XOR-swizzled (swz128) on the
-// SOURCE address (the LDS image written by the DMA is lane-linear) and on the ds_read_b128.
+// One kernel template, two tile shapes (16x16x32 MFMA, BK = 64):
+//   256x256 tile, 8 waves (2 M x 4 N, 128x64 per wave), 128 KiB LDS, 1 workgroup/CU  — the
+//     encoder GEMMs (M = tokens of a step).  Per K tile a wave issues 24 ds_read_b128 for 64
+//     MFMAs: half the LDS traffic per flop of the 128x128 tile.
+//   128x128 tile, 4 waves (2 x 2, 64x64 per wave), 64 KiB LDS — small M (pooler, trimmed layer).
+// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop), double-buffered;
+// the next K tile's DMA is issued before the current tile's MFMAs, one barrier per K tile.  LDS
+// rows are 128 B; 16-B chunks are XOR-swizzled (swz128) on the SOURCE address (the image the DMA
+// writes is lane-linear) and on the ds_read_b128: conflict-free operand reads.
 // MFMA orientation: a = W fragment (rows n), b = activation fragment (cols m), so each lane ends
 // with 4 consecutive n of one row m -> 8/16-byte row-major stores.
 #include "common.h"
@@ -15,18 +21,22 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+constexpr int BK = 64;
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const bf16_t* __restrict__ res, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
     int ldo, int ldres, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A 16K | W 16K]
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;  // 1-KiB DMA pieces per wave
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A | W]
 
-  // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch), give each
-  // XCD a contiguous run of tiles so neighbouring tiles (same A panel) hit one L2.
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each
+  // XCD a contiguous run of tiles, n fastest, so neighbouring tiles (same A panel) hit one L2.
   const int nwg = tiles_m * tiles_n;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -37,40 +47,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
+  const int wm = w / WAVES_N, wn = w % WAVES_N;
 
-  // ---- DMA source pointers: instruction q of wave w fills LDS rows (q*4+w)*8 .. +8
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
+  // ---- DMA source pointers: piece p = q*NW + w fills LDS rows 8p .. 8p+7 (1 KiB, lane-linear)
+  const bf16_t* a_src[A_PIECES];
+  const bf16_t* w_src[W_PIECES];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (q * 4 + w) * 8 + (lane >> 3);
-    const int chunk = swz128(row, lane & 7);
-    const int ar = min(mb + row, M - 1), wr = min(nb + row, N - 1);
-    a_src[q] = A + (size_t)ar * lda + chunk * 8;
-    w_src[q] = W + (size_t)wr * ldw + chunk * 8;
+  for (int q = 0; q < A_PIECES; ++q) {
+    const int row = (q * NW + w) * 8 + (lane >> 3);
+    a_src[q] = A + (size_t)min(mb + row, M - 1) * lda + swz128(row, lane & 7) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < W_PIECES; ++q) {
+    const int row = (q * NW + w) * 8 + (lane >> 3);
+    w_src[q] = W + (size_t)min(nb + row, N - 1) * ldw + swz128(row, lane & 7) * 8;
   }
   auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * (2 * TILE_BYTES);
+    char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < A_PIECES; ++q)
       __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + kt * BK),
-                                       LDS_PTR(base + (q * 4 + w) * 1024), 16, 0, 0);
+                                       LDS_PTR(base + (q * NW + w) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < W_PIECES; ++q)
       __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[q] + kt * BK),
-                                       LDS_PTR(base + TILE_BYTES + (q * 4 + w) * 1024), 16, 0, 0);
-    }
+                                       LDS_PTR(base + A_BYTES + (q * NW + w) * 1024), 16, 0, 0);
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[TN][TM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int lsw = (fr >> 1) & 7;  // swizzle key of this lane's rows (row = 16*i + fr)
-  const int a_off = (wm * 64 + fr) * 128;
-  const int w_off = TILE_BYTES + (wn * 64 + fr) * 128;
+  const int lsw = (fr >> 1) & 7;  // swizzle key of this lane's rows (row = 16*t + fr)
+  const int a_off = (wm * TM * 16 + fr) * 128;
+  const int w_off = A_BYTES + (wn * TN * 16 + fr) * 128;
 
   const int nt = K / BK;
   stage(0, 0);
@@ -78,34 +91,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-    const char* base = smem + (t & 1) * (2 * TILE_BYTES);
+    const char* base = smem + (t & 1) * BUF_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + fq) ^ lsw) * 16;
-      bf16x8_t af[4], wf[4];
+      bf16x8_t af[TM], wf[TN];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        af[j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TN; ++i)
         wf[i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < TM; ++j)
+        af[j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
   }
 
   // ---- epilogue: lane holds n = n0..n0+3 of row m for every (i,j)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n0 = nb + wn * 64 + i * 16 + fq * 4;
+  for (int i = 0; i < TN; ++i) {
+    const int n0 = nb + (wn * TN + i) * 16 + fq * 4;
     if (n0 >= N) continue;
     const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mb + wm * 64 + j * 16 + fr;
+    for (int j = 0; j < TM; ++j) {
+      const int m = mb + (wm * TM + j) * 16 + fr;
       if (m >= M) continue;
       float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
       float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
@@ -129,20 +142,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32>
-hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN>
+hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+  constexpr int LDS = 2 * (BM + BN) * BK * 2;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  auto kfn = gemm_bf16_kernel<EPI, OUT_F32>;
-  static bool attr_set = false;  // per instantiation
+  auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN>;
+  static bool attr_set = false;  // per instantiation; one process drives one GPU
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, st, g.A, g.W, g.bias,
-                     g.res, g.out, g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n), dim3(64 * WAVES_M * WAVES_N), LDS, st, g.A, g.W,
+                     g.bias, g.res, g.out, g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldres, tiles_m,
+                     tiles_n);
   return hipGetLastError();
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
+  // big tile once it fills the chip about once over; the small tile otherwise
+  const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+  if (g.tile == 256 || (g.tile == 0 && big_tiles >= 192 && g.N % 256 == 0))
+    return launch_cfg<EPI, OUT_F32, 2, 4, 8, 4>(g, st);
+  return launch_cfg<EPI, OUT_F32, 2, 2, 4, 4>(g, st);
 }
 
 }  // namespace
@@ -154,6 +179,7 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.lda % 8 || g.ldw % 8 || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
+  if (g.tile != 0 && g.tile != 128 && g.tile != 256) return "gemm: tile must be 0 (auto), 128 or 256";
   return nullptr;
 }
 

@@ -13,6 +13,7 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres;
   int epi;
   bool out_f32;
+  int tile = 0;  // 0 auto, 128 or 256: tile edge (tests pin each shape)
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);

@@ -92,11 +92,12 @@ int clip_bce_loss(const float* dev_logits, const float* dev_targets, int32_t cou
 /* ---- single-kernel entry points (parity tests drive each kernel through the ABI) ---- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias): epi 0 bias, 1 bias+erf-GELU, 2 bias+residual, 3 bias+tanh
  * (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463). A, W, res are bf16; out bf16 or
- * fp32 (out_f32). Leading dimensions in elements. */
+ * fp32 (out_f32). Leading dimensions in elements. tile: 0 = choose, 128 / 256 = force that
+ * workgroup tile edge. */
 int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
                    const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
-                   int32_t out_f32, void* stream);
+                   int32_t out_f32, int32_t tile, void* stream);
 /* softmax(q k^T) v per packed sequence and head (modeling_bert.py:111-136), q pre-scaled;
  * qkv bf16 [T, 3*hidden], ctx bf16 [T, hidden], head_dim 64. */
 int clip_attention_varlen(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens,

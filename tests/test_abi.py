@@ -30,4 +30,4 @@ def test_argument_errors_without_a_device():
     assert b"null" in lib.clip_last_error()
     assert lib.clip_load_weight(None, b"x", None, 0) == _lib.CLIP_ERR_ARG
     assert lib.clip_epilogue(None, None, 0.05, 1, 7, None, None, None, None, None) == _lib.CLIP_ERR_ARG
-    assert lib.clip_gemm_bf16(None, None, None, None, None, 16, 16, 100, 100, 100, 16, 0, 0, 1, None) == _lib.CLIP_ERR_ARG
+    assert lib.clip_gemm_bf16(None, None, None, None, None, 16, 16, 100, 100, 100, 16, 0, 0, 1, 0, None) == _lib.CLIP_ERR_ARG

@@ -20,13 +20,13 @@ def _sync():
     torch.cuda.synchronize()
 
 
-def _gemm(lib, A, W, bias, res, epi, out_f32):
+def _gemm(lib, A, W, bias, res, epi, out_f32, tile=0):
     M, K = A.shape
     N = W.shape[0]
     out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
     _lib.check(lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out),
                                   M, N, K, A.stride(0), W.stride(0), out.stride(0),
-                                  0 if res is None else res.stride(0), epi, int(out_f32), _lib.stream_ptr()))
+                                  0 if res is None else res.stride(0), epi, int(out_f32), tile, _lib.stream_ptr()))
     _sync()
     return out
 
@@ -41,7 +41,8 @@ def _gemm(lib, A, W, bias, res, epi, out_f32):
     (48, 768, 768, 3, False),         # pooler tanh, M < tile
     (1, 128, 128, 0, True),
 ])
-def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, tile):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + epi)
     A = (torch.randn(M, K, generator=g) * 1.0).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
@@ -49,7 +50,7 @@ def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
     W[:, 0] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.01
     bias = torch.randn(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
-    out = _gemm(lib, A, W, bias, res, epi, out_f32).float()
+    out = _gemm(lib, A, W, bias, res, epi, out_f32, tile).float()
     ref = A.float() @ W.float().T + bias
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
@@ -69,7 +70,7 @@ def test_gemm_rejects_bad_shapes(lib):
     W = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
     b = torch.zeros(16, device="cuda")
     o = torch.zeros(16, 16, device="cuda")
-    rc = lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), None, _lib.ptr(o), 16, 16, 100, 100, 100, 16, 0, 0, 1, None)
+    rc = lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), None, _lib.ptr(o), 16, 16, 100, 100, 100, 16, 0, 0, 1, 0, None)
     assert rc == _lib.CLIP_ERR_ARG and b"multiple of 64" in lib.clip_last_error()
 
 
