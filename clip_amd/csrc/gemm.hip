@@ -22,6 +22,9 @@
 namespace {
 
 constexpr int BK = 64;
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA, 2 no DMA in loop, 3 no epilogue stores
+#endif
 
 template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
@@ -90,53 +93,122 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    if (t + 1 < nt && GEMM_ABLATE != 2) stage(t + 1, (t + 1) & 1);
     const char* base = smem + (t & 1) * BUF_BYTES;
+    // all 2 x (TN + TM) fragment reads of the tile are issued up front; the compiler's counted
+    // lgkmcnt waits let the first MFMAs start while the later reads are still in flight
+    bf16x8_t af[2][TM], wf[2][TN];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + fq) ^ lsw) * 16;
-      bf16x8_t af[TM], wf[TN];
 #pragma unroll
       for (int i = 0; i < TN; ++i)
-        wf[i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
+        wf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        af[j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
+        af[ks][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-    }
+          if (GEMM_ABLATE == 1) {
+            asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][j]));
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+          }
   }
 
-  // ---- epilogue: lane holds n = n0..n0+3 of row m for every (i,j)
+  // ---- epilogue.  Lane holds n = 16 i + 4 fq .. +3 of row m = 16 j + fr for every (i, j): stored
+  // straight from the accumulators that is 16 rows x 32 B per instruction (measured ~2 TB/s).
+  // Instead each wave transposes its (16 TM) x 64 sub-tile through its own 16-KiB slice of the
+  // (now idle) staging LDS and writes whole 128-B (bf16) / 256-B (f32) row segments, 16 B per lane.
+  static_assert(TN == 4, "epilogue assumes 64 output columns per wave");
+  __syncthreads();  // every wave is done reading the last K tile
+  char* ep = smem + w * 16384;
+  float4 bv[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
-    const int n0 = nb + (wn * TN + i) * 16 + fq * 4;
-    if (n0 >= N) continue;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
+    const int n0 = min(nb + (wn * TN + i) * 16 + fq * 4, N - 4);
+    bv[i] = *reinterpret_cast<const float4*>(bias + n0);
+  }
+  const int m_base = mb + wm * TM * 16, n_base = nb + wn * 64;
+  if (!OUT_F32) {
+    // LDS image [16 TM rows][128 B]; 8-byte slots XOR-swizzled in pairs so 16-B reads stay whole
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = mb + (wm * TM + j) * 16 + fr;
-      if (m >= M) continue;
-      float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
-      float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-      if (EPI == EPI_BIAS_GELU) {
-        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
-      } else if (EPI == EPI_BIAS_TANH) {
-        v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
-      } else if (EPI == EPI_BIAS_RES) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n0);
-        v0 += __uint_as_float(rv.x << 16); v1 += __uint_as_float(rv.x & 0xffff0000u);
-        v2 += __uint_as_float(rv.y << 16); v3 += __uint_as_float(rv.y & 0xffff0000u);
-      }
-      if (OUT_F32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n0) =
-            make_float4(v0, v1, v2, v3);
-      } else {
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldo + n0) =
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+        float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+        if (EPI == EPI_BIAS_GELU) {
+          v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        } else if (EPI == EPI_BIAS_TANH) {
+          v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
+        }
+        const int row = j * 16 + fr, slot = (i * 4 + fq) ^ ((row & 7) << 1);
+        if (GEMM_ABLATE == 3) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3)); continue; }
+        *reinterpret_cast<uint2*>(ep + row * 128 + slot * 8) =
             make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+#pragma unroll
+    for (int p = 0; p < TM * 2; ++p) {
+      const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+      const int m = m_base + row, n = n_base + c16 * 8;
+      uint4 v = *reinterpret_cast<const uint4*>(ep + row * 128 + ((c16 ^ (row & 7)) * 16));
+      if (GEMM_ABLATE == 3) continue;
+      if (m < M && n < N) {
+        if (EPI == EPI_BIAS_RES) {
+          const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+          const uint32_t* vi = reinterpret_cast<const uint32_t*>(&v);
+          const uint32_t* ri = reinterpret_cast<const uint32_t*>(&r);
+          uint32_t o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16x2(__uint_as_float(vi[k] << 16) + __uint_as_float(ri[k] << 16),
+                               __uint_as_float(vi[k] & 0xffff0000u) + __uint_as_float(ri[k] & 0xffff0000u));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldo + n) = v;
+      }
+    }
+  } else {
+    // f32: passes of 64 rows; LDS image [64 rows][256 B], 16-byte slots XOR-swizzled by row
+#pragma unroll
+    for (int ps = 0; ps < TM / 4; ++ps) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = ps * 4 + jj;
+          float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+          float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+          if (EPI == EPI_BIAS_GELU) {
+            v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+          } else if (EPI == EPI_BIAS_TANH) {
+            v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
+          }
+          const int row = jj * 16 + fr, slot = (i * 4 + fq) ^ (row & 15);
+          if (GEMM_ABLATE == 3) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3)); continue; }
+          *reinterpret_cast<float4*>(ep + row * 256 + slot * 16) = make_float4(v0, v1, v2, v3);
+        }
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int row = p * 4 + (lane >> 4), c16 = lane & 15;
+        const int m = m_base + ps * 64 + row, n = n_base + c16 * 4;
+        float4 v = *reinterpret_cast<const float4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16));
+        if (GEMM_ABLATE == 3) continue;
+        if (m < M && n < N) {
+          if (EPI == EPI_BIAS_RES) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n);
+            v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+            v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+          }
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n) = v;
+        }
       }
     }
   }
