@@ -34,6 +34,7 @@ SIGNATURES = {
     "clip_load_weight": [_p, C.c_char_p, _p, _i64],
     "clip_finalize_weights": [_p],
     "clip_focus_index": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "clip_prepare_packed": [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],

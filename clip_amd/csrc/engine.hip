@@ -283,6 +283,16 @@ int clip_focus_index(const int32_t* ids, const int32_t* cu, int32_t n_seqs, int3
   return CLIP_OK;
 }
 
+int clip_prepare_packed(const int32_t* ids, const int32_t* cu, int32_t n_seqs, int32_t sep_id,
+                        int32_t n_ctx, int32_t* type_ids, int32_t* pos_ids, int32_t* focus,
+                        int32_t* err, void* stream) {
+  if (!ids || !cu || !type_ids || !pos_ids || !focus || !err || n_seqs < 0)
+    return fail(CLIP_ERR_ARG, "clip_prepare_packed: bad argument");
+  HIP_TRY(launch_prepare_packed(ids, cu, n_seqs, sep_id, n_ctx, type_ids, pos_ids, focus, err,
+                                (hipStream_t)stream));
+  return CLIP_OK;
+}
+
 int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_ids,
                         const int32_t* pos_ids, const int32_t* cu, const int32_t* focus,
                         int32_t n_seqs, int32_t T, int32_t max_seqlen, int32_t head_kind,

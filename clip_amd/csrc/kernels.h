@@ -44,6 +44,9 @@ hipError_t launch_classifier(const bf16_t* x, const int32_t* rows, const float* 
 hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
                               int sep_id, int n_ctx, int32_t* focus, int32_t* err,
                               hipStream_t st);
+hipError_t launch_prepare_packed(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
+                                 int sep_id, int n_ctx, int32_t* type_ids, int32_t* pos_ids,
+                                 int32_t* focus, int32_t* err, hipStream_t st);
 // fused scoring epilogue (ref: apply_bert_unlabeled.py:111-124, test_load.py:37-38)
 hipError_t launch_epilogue(const float* logits, const double* label_thresh, float any_thresh,
                            int n, int L, float* probs, float* max_score, uint8_t* labels,

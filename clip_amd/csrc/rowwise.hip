@@ -177,6 +177,46 @@ __global__ __launch_bounds__(64) void focus_index_kernel(const int32_t* __restri
   }
 }
 
+// Everything the packed forward needs besides the token ids, from the ids alone, one wave per row:
+//   pos_ids[t]  = t - row start                       (transformers BertEmbeddings position_ids)
+//   type_ids[t] = 0 iff exactly n_ctx separators lie at or before t, else 1
+//                 (ref: sentclf/bert.py:168-176: [0, sep[n-1]) -> 1, [sep[n-1], sep[n]) -> 0,
+//                  [sep[n], end) -> 1; n_ctx <= 0: all 0, the sentence-only collator)
+//   focus[s]    = index of the (n_ctx+1)-th separator (bert_model.py:52) or the row's first token
+__global__ __launch_bounds__(64) void prepare_packed_kernel(const int32_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ cu,
+                                                            int sep_id, int n_ctx,
+                                                            int32_t* __restrict__ type_ids,
+                                                            int32_t* __restrict__ pos_ids,
+                                                            int32_t* __restrict__ focus,
+                                                            int32_t* __restrict__ err) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int beg = cu[s], end = cu[s + 1];
+  int count = 0, found = -1;
+  for (int t0 = beg; t0 < end; t0 += 64) {
+    const int t = t0 + lane;
+    const bool hit = n_ctx > 0 && t < end && ids[t] == sep_id;
+    const unsigned long long m = __ballot(hit);
+    const int incl = count + __popcll(m & ((2ull << lane) - 1));  // separators at or before t
+    if (t < end) {
+      pos_ids[t] = t - beg;
+      type_ids[t] = (n_ctx > 0 && incl != n_ctx) ? 1 : 0;
+    }
+    const int c = __popcll(m);
+    if (found < 0 && n_ctx > 0 && count + c > n_ctx) {
+      int k = n_ctx - count;
+      unsigned long long mm = m;
+      while (k-- > 0) mm &= mm - 1;
+      found = t0 + __ffsll((long long)mm) - 1;
+    }
+    count += c;
+  }
+  if (lane == 0) {
+    focus[s] = (n_ctx > 0 && found >= 0) ? found : beg;
+    if (n_ctx > 0 && count != 2 * n_ctx + 1) atomicOr(err, 1);
+  }
+}
+
 // 8 lanes per sentence (lane j<L holds label j), wave-shuffle max / any over the label axis.
 __global__ __launch_bounds__(256) void epilogue_kernel(const float* __restrict__ logits,
                                                        const double* __restrict__ label_thresh,
@@ -283,6 +323,15 @@ hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int
   if (n_seqs <= 0) return hipSuccess;
   hipLaunchKernelGGL(focus_index_kernel, dim3(n_seqs), dim3(64), 0, st, ids, cu_seqlens, n_seqs,
                      sep_id, n_ctx, focus, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_packed(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
+                                 int sep_id, int n_ctx, int32_t* type_ids, int32_t* pos_ids,
+                                 int32_t* focus, int32_t* err, hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(prepare_packed_kernel, dim3(n_seqs), dim3(64), 0, st, ids, cu_seqlens, sep_id,
+                     n_ctx, type_ids, pos_ids, focus, err);
   return hipGetLastError();
 }
 

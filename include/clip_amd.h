@@ -64,6 +64,15 @@ int clip_focus_index(const int32_t* dev_ids, const int32_t* dev_cu_seqlens, int3
                      int32_t sep_id, int32_t n_ctx, int32_t* dev_focus, int32_t* dev_err,
                      void* stream);
 
+/* Replaces the per-batch tensor building of the collators for PACKED rows, on the device, from the
+ * token ids alone: token-type ids exactly as sentclf/bert.py:168-176 assigns them (type 0 on the
+ * [SEP] before the focus and on the focus tokens, 1 elsewhere; all 0 when n_ctx <= 0 as
+ * sentclf/bert.py:44-68 passes none), position ids 0..len-1 (modeling_bert.py:65,83) and the focus
+ * index of clip_focus_index (n_ctx <= 0: the row's first token).  dev_err as clip_focus_index. */
+int clip_prepare_packed(const int32_t* dev_ids, const int32_t* dev_cu_seqlens, int32_t n_seqs,
+                        int32_t sep_id, int32_t n_ctx, int32_t* dev_type_ids, int32_t* dev_pos_ids,
+                        int32_t* dev_focus, int32_t* dev_err, void* stream);
+
 /* Replaces model(**inputs) (apply_bert_unlabeled.py:110; test_load.py:36; bert_model.py:66-103
  * and :210-251) on PACKED rows: token t of sequence s sits at dev_ids[cu_seqlens[s] + t]; the
  * key-padding mask of the reference (modeling_bert.py:688-708) is replaced by the packing.
