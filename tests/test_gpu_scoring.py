@@ -81,11 +81,15 @@ def test_bulk_scorer_vs_oracle_many_ragged_rows(n_ctx):
     p_ref, keep_ref, score_ref, _ = O.score_rows(sd, cfg, rows, n_ctx, batch_size=8)
     assert np.abs(res.probs - p_ref).max() < 2e-3
     assert np.abs(res.max_score - score_ref).max() < 2e-3
-    # rank agreement of the top-50 by max_label_score, ties aside: same set up to score tolerance
+    # top-50 by max_label_score: every row the engine ranks in its top-k is, by the oracle's score,
+    # within the 2e-3 score tolerance of the oracle's k-th score (exact order needs identical scores)
     k = 50
     mine = topk.local_topk(res.doc_ids, res.sent_ixs, res.max_score, k)
     theirs = topk.local_topk(res.doc_ids, res.sent_ixs, score_ref, k)
-    assert len(set(mine["sent_ix"]) & set(theirs["sent_ix"])) >= k - 5
+    assert score_ref[mine["sent_ix"]].min() >= theirs["score"].min() - 4e-3
+    # and with identical scores the order is bit-exact
+    again = topk.local_topk(res.doc_ids, res.sent_ixs, res.max_score.copy(), k)
+    assert np.array_equal(mine, again)
 
 
 def test_bulk_scorer_flags_wrong_sep_count(golden):
