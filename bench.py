@@ -37,20 +37,19 @@ def flops_per_row(L, cfg):
     return cfg.num_hidden_layers * (2 * L * (4 * H * H + 2 * H * I) + 4 * L * L * H) + 2 * H * cfg.num_labels
 
 
-def make_batch(rows, n_ctx, device):
+def make_batch(rows, device):
+    """What the host ships per step: packed token ids + row offsets (everything else is derived on
+    the device by clip_prepare_packed)."""
     lens = np.asarray([len(r) for r in rows], np.int32)
     ids = np.concatenate(rows).astype(np.int32)
     cu = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
-    pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
-    # token types of sentclf/bert.py:168-176 on packed rows
-    tt = np.zeros_like(ids)
-    for s, (b, e) in enumerate(zip(cu[:-1], cu[1:])):
-        sep = np.nonzero(ids[b:e] == 102)[0]
-        tt[b:b + sep[n_ctx - 1]] = 1
-        tt[b + sep[n_ctx]:e] = 1
     t = lambda a: torch.from_numpy(a).to(device)
-    return {"ids": t(ids), "tt": t(tt), "pos": t(pos), "cu": t(cu), "max_len": int(lens.max()),
-            "n": len(rows), "tokens": int(lens.sum()), "lens": lens}
+    T, n = int(lens.sum()), len(rows)
+    return {"ids": t(ids), "cu": t(cu), "max_len": int(lens.max()), "n": n, "tokens": T, "lens": lens,
+            "tt": torch.empty(T, dtype=torch.int32, device=device),
+            "pos": torch.empty(T, dtype=torch.int32, device=device),
+            "focus": torch.empty(n, dtype=torch.int32, device=device),
+            "logits": torch.empty((n, 7), dtype=torch.float32, device=device)}
 
 
 def main():
@@ -92,8 +91,9 @@ def main():
     # two resident batches per rank (documents are sharded by rank: different seeds = different rows)
     all_rows = synth.context_rows(2 * args.rows_per_step, n_ctx, cfg.vocab_size, seed=1002 + 17 * rank,
                                   fixed_len=args.seq_len)
-    batches = [make_batch(all_rows[i * args.rows_per_step:(i + 1) * args.rows_per_step], n_ctx, device)
+    batches = [make_batch(all_rows[i * args.rows_per_step:(i + 1) * args.rows_per_step], device)
                for i in range(2)]
+    err = torch.zeros(1, dtype=torch.int32, device=device)
     thr = torch.tensor(DNOTE_THRESHS, dtype=torch.float64, device=device)
     n = args.rows_per_step
     out = {"max": torch.empty(n, device=device), "keep": torch.empty(n, dtype=torch.uint8, device=device),
@@ -101,10 +101,16 @@ def main():
     stream = _lib.stream_ptr()
 
     def step(b):
-        logits = model.forward_packed(b["ids"], b["tt"], b["pos"], b["cu"], b["max_len"], check=False)
-        _lib.check(lib.clip_epilogue(_lib.ptr(logits), _lib.ptr(thr), 0.05, b["n"], cfg.num_labels, None,
+        # the hot path of one step, all on the current stream, nothing allocated:
+        # ids -> (type ids, positions, focus [SEP]) -> encoder + classifier -> sigmoid/threshold/max
+        _lib.check(lib.clip_prepare_packed(_lib.ptr(b["ids"]), _lib.ptr(b["cu"]), b["n"], 102, n_ctx,
+                                           _lib.ptr(b["tt"]), _lib.ptr(b["pos"]), _lib.ptr(b["focus"]),
+                                           _lib.ptr(err), stream))
+        _lib.check(lib.clip_forward_packed(engine, _lib.ptr(b["ids"]), _lib.ptr(b["tt"]), _lib.ptr(b["pos"]),
+                                           _lib.ptr(b["cu"]), _lib.ptr(b["focus"]), b["n"], b["tokens"],
+                                           b["max_len"], 0, _lib.ptr(b["logits"]), stream))
+        _lib.check(lib.clip_epilogue(_lib.ptr(b["logits"]), _lib.ptr(thr), 0.05, b["n"], cfg.num_labels, None,
                                      _lib.ptr(out["max"]), _lib.ptr(out["labels"]), _lib.ptr(out["keep"]), stream))
-        return logits
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,6 +138,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # end-of-job stage (outside the timed steps): local top-k + ONE all-gather + deterministic merge
+    from clip_amd import topk
+    step(batches[0])
+    torch.cuda.synchronize()
+    scores = out["max"].cpu().numpy()
+    t_k = time.perf_counter()
+    local = topk.local_topk(np.full(n, rank, np.int64), np.arange(n), scores, 64, keep=out["keep"].cpu().numpy() != 0)
+    glob = topk.global_topk(local, 64)
+    topk_ms = (time.perf_counter() - t_k) * 1e3
+
     if rank == 0:
         rows_total = world * args.rows_per_step * args.steps
         value = rows_total / elapsed
@@ -158,6 +174,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
         }
+        res["topk"] = {"k": 64, "records": int(len(glob)), "ms_local_select_allgather_merge": round(topk_ms, 3)}
         if args.breakdown:
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
         if world == 1 and not args.no_cpu_baseline:
@@ -171,8 +188,10 @@ def main():
                 "kind": "port", "sample": f"first {len(sample)} rows of the same workload, batch 8 padded "
                 f"(apply_bert_unlabeled.py:92 semantics), torch {torch.__version__} fp32 CPU oracle, {dt:.1f} s"}
             # the same rows through the GPU path, as a live parity check beside the numbers
-            g = model.forward_packed(batches[0]["ids"], batches[0]["tt"], batches[0]["pos"], batches[0]["cu"],
-                                     batches[0]["max_len"]).cpu().numpy()[:len(sample)]
+            step(batches[0])
+            torch.cuda.synchronize()
+            assert int(err.item()) == 0
+            g = batches[0]["logits"].cpu().numpy()[:len(sample)]
             res["parity_vs_cpu_oracle_max_abs_logit"] = float(np.abs(g - logits_ref).max())
         print(json.dumps(res), flush=True)
     if dist is not None:
