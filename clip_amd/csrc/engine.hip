@@ -156,7 +156,7 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   clip_engine* e = new clip_engine();
   e->cfg = *c;
   e->device = device_id;
-  const size_t Tp = ((size_t)c->max_tokens + 127) / 128 * 128, H = c->hidden_size,
+  const size_t Tp = ((size_t)c->max_tokens + 255) / 256 * 256, H = c->hidden_size,
                I = c->intermediate_size, S = ((size_t)c->max_seqs + 127) / 128 * 128;
   int rc = 0;
   rc = rc ? rc : dev_alloc(e, (void**)&e->x, Tp * H * 2);
@@ -169,6 +169,18 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   if (rc) {
     clip_destroy(e);
     return rc;
+  }
+  // rows between a call's token count and the next multiple of 256 are computed (never used) by the
+  // persistent GEMM: keep them finite from the start
+  hipError_t me = hipSuccess;
+  if (me == hipSuccess) me = hipMemset(e->x, 0, Tp * H * 2);
+  if (me == hipSuccess) me = hipMemset(e->qkv, 0, Tp * 3 * H * 2);
+  if (me == hipSuccess) me = hipMemset(e->ctx, 0, Tp * H * 2);
+  if (me == hipSuccess) me = hipMemset(e->mid, 0, Tp * I * 2);
+  if (me == hipSuccess) me = hipMemset(e->preln, 0, Tp * H * 4);
+  if (me != hipSuccess) {
+    clip_destroy(e);
+    return fail(CLIP_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(me));
   }
   *out = e;
   return CLIP_OK;
@@ -322,11 +334,12 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
                             c.type_vocab_size, st));
   }
   GemmArgs g;
+  const int Tg = (T + 255) / 256 * 256;  // GEMM rows: whole 256-row tiles (workspace is padded)
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
     {
       ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
-      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, T, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
       HIP_TRY(launch_gemm(g, st));
     }
     {
@@ -335,7 +348,7 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, T, H, H, H, H, H, H, EPI_BIAS_RES, true};
+      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, Tg, H, H, H, H, H, H, EPI_BIAS_RES, true};
       HIP_TRY(launch_gemm(g, st));
     }
     {
@@ -344,12 +357,12 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
-      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, T, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
       HIP_TRY(launch_gemm(g, st));
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, T, H, I, I, I, H, H, EPI_BIAS_RES, true};
+      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, Tg, H, I, I, I, H, H, EPI_BIAS_RES, true};
       HIP_TRY(launch_gemm(g, st));
     }
     {

@@ -251,11 +251,15 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.lda % 8 || g.ldw % 8 || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
-  if (g.tile != 0 && g.tile != 128 && g.tile != 256) return "gemm: tile must be 0 (auto), 128 or 256";
+  if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1) return "gemm: tile must be 0 (auto), 1 (persistent), 128 or 256";
+  if (g.tile == 1 && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
   return nullptr;
 }
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.tile == 1 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
+                      !(g.epi == EPI_BIAS_TANH && g.out_f32)))
+    return launch_gemm_persist(g, st);
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_one<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_one<EPI_BIAS, true>(g, st);

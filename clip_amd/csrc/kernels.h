@@ -13,10 +13,12 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres;
   int epi;
   bool out_f32;
-  int tile = 0;  // 0 auto, 128 or 256: tile edge (tests pin each shape)
+  int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip)
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
+bool gemm_persist_ok(const GemmArgs& g);
+hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st);
 
 // varlen self-attention over packed sequences; qkv [T, 3H] bf16 (q | k | v, heads of 64),
 // q pre-scaled by 1/sqrt(64); ctx [T, H] bf16. One workgroup per (128-row q tile, sequence, head).

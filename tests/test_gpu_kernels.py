@@ -65,6 +65,38 @@ def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, tile):
     assert (out - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K,epi,out_f32", [
+    (256, 256, 128, 0, True),         # one tile, two K steps
+    (2048, 768, 768, 2, True),        # fewer tiles than CUs: some workgroups idle
+    (66 * 256, 2304, 768, 0, False),  # 594 tiles over 256 workgroups: 2-3 tiles each, uneven
+    (40 * 256, 3072, 768, 1, False),
+    (72 * 256, 768, 3072, 2, True),
+    (36 * 256, 768, 768, 2, False),
+])
+def test_persistent_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
+    g = torch.Generator(device="cpu").manual_seed(M + N * 3 + K + epi)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    W[:, 0] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.01
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
+    out = _gemm(lib, A, W, bias, res, epi, out_f32, 1).float()
+    ref = A.float() @ W.float().T + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = ref + res.float()
+    tol = 2e-3 + (0 if out_f32 else 8e-3 * ref.abs().max().item())
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < tol
+    # run-to-run determinism (a race in the DMA / barrier protocol shows up as flicker)
+    out2 = _gemm(lib, A, W, bias, res, epi, out_f32, 1).float()
+    assert torch.equal(out, out2)
+    # and identical to the one-tile-per-workgroup kernel: same MFMA order per output element
+    out3 = _gemm(lib, A, W, bias, res, epi, out_f32, 256).float()
+    assert torch.equal(out, out3)
+
+
 def test_gemm_rejects_bad_shapes(lib):
     A = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
     W = torch.zeros(16, 100, dtype=torch.bfloat16, device="cuda")
