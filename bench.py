@@ -37,6 +37,12 @@ def flops_per_row(L, cfg):
     return cfg.num_hidden_layers * (2 * L * (4 * H * H + 2 * H * I) + 4 * L * L * H) + 2 * H * cfg.num_labels
 
 
+def flops_saved_per_row(L, cfg):
+    """Last-layer trimming: past the K/V projection only the pooled row is computed."""
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    return 2 * (L - 1) * (H * H + 2 * H * I) + 4 * L * H * (L - 1)
+
+
 def make_batch(rows, device):
     """What the host ships per step: packed token ids + row offsets (everything else is derived on
     the device by clip_prepare_packed)."""
@@ -168,7 +174,9 @@ def main():
                        "rows_per_step": args.rows_per_step, "seq_len": args.seq_len,
                        "sharding": f"documents over {world} rank(s), no collective while scoring"},
             "model_tflops_per_gpu": round(model_flops * args.steps / elapsed / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_BIAS_GELU> (FFN up, M=%d N=%d K=%d)" % (T, I, H),
+            "executed_tflops_per_gpu": round((model_flops - sum(flops_saved_per_row(int(L), cfg) for L in batches[0]["lens"]))
+                                             * args.steps / elapsed / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
@@ -179,7 +187,7 @@ def main():
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bert_oracle as O    # CPU baseline leg only
-            sample = all_rows[:64]
+            sample = all_rows[:256]
             t1 = time.perf_counter()
             _, keep_ref, score_ref, logits_ref = O.score_rows(sd, cfg, sample, n_ctx, batch_size=8)
             dt = time.perf_counter() - t1

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("CLIP_AMD_LIB") or os.path.join(_HERE, "lib", "libclip
 
 CLIP_OK, CLIP_ERR_ARG, CLIP_ERR_HIP, CLIP_ERR_STATE, CLIP_ERR_CAPACITY, CLIP_ERR_SEP_COUNT = 0, -1, -2, -3, -4, -5
 KINDS = ("embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up",
-         "gemm_ffn_down", "head")
+         "gemm_ffn_down", "head", "last_layer_rows")
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH = 0, 1, 2, 3
 
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "clip_layernorm": [_p, _p, _p, _f, _p, _i32, _i32, _p],
     "clip_embed_layernorm": [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_set_trim_last_layer": [_p, _i32],
     "clip_profile_enable": [_p, C.c_uint32],
     "clip_profile_read": [_p, _p, _p, _i32],
     "clip_last_error": [],

@@ -189,7 +189,75 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   }
 }
 
+// Last-layer form: only the pooled token of each sequence is consumed downstream
+// (ref: sentclf/bert_model.py:52-58 gathers ONE hidden row per sentence; :234 uses row 0), so its
+// attention output is the only one needed: one wave per (sequence, head), q row against all keys.
+// HBM-bound (reads every K and V row once); softmax weights stay fp32.
+__global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __restrict__ qkv,
+                                                             const int32_t* __restrict__ cu,
+                                                             const int32_t* __restrict__ focus,
+                                                             bf16_t* __restrict__ ctx_rows,
+                                                             int hidden) {
+  __shared__ float q_s[HD];
+  __shared__ float p_s[512];
+  const int seq = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  const int beg = cu[seq], len = min(cu[seq + 1] - beg, 512);
+  const int ld = 3 * hidden;
+  const bf16_t* kbase = qkv + (size_t)beg * ld + hidden + head * HD;
+  const bf16_t* vbase = kbase + hidden;
+  q_s[lane] = bf16_to_f32(qkv[(size_t)focus[seq] * ld + head * HD + lane]);
+  __syncthreads();
+  float sc[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int key = lane + 64 * i;
+    float d = -INFINITY;
+    if (key < len) {
+      d = 0.f;
+      const uint4* kr = reinterpret_cast<const uint4*>(kbase + (size_t)key * ld);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint4 kv = kr[c];
+        const uint32_t wds[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          d = fmaf(__uint_as_float(wds[e] << 16), q_s[c * 8 + 2 * e], d);
+          d = fmaf(__uint_as_float(wds[e] & 0xffff0000u), q_s[c * 8 + 2 * e + 1], d);
+        }
+      }
+      d *= LOG2E;
+    }
+    sc[i] = d;
+    mx = fmaxf(mx, d);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int key = lane + 64 * i;
+    const float p = key < len ? exp2f(sc[i] - mx) : 0.f;
+    sum += p;
+    p_s[key] = p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  for (int key = 0; key < len; ++key) o = fmaf(p_s[key], bf16_to_f32(vbase[(size_t)key * ld + lane]), o);
+  ctx_rows[(size_t)seq * hidden + head * HD + lane] = f32_to_bf16(o / sum);
+}
+
 }  // namespace
+
+hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
+                                  const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
+                                  int hidden, hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  if (hidden != n_heads * HD) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attention_focus_kernel, dim3(n_seqs, n_heads), dim3(64), 0, st, qkv, cu_seqlens,
+                     focus, ctx_rows, hidden);
+  return hipGetLastError();
+}
 
 hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
                             int max_seqlen, int n_heads, int hidden, hipStream_t st) {

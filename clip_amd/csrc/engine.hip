@@ -61,8 +61,9 @@ struct clip_engine {
   float *bpool = nullptr, *wcls = nullptr, *bcls = nullptr;
   // workspace
   bf16_t *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
-         *pooled = nullptr;
-  float* preln = nullptr;
+         *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr;
+  float *preln = nullptr, *preln_rows = nullptr;
+  bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
   std::vector<hipEvent_t> ev_pool;
@@ -166,6 +167,9 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   rc = rc ? rc : dev_alloc(e, (void**)&e->preln, Tp * H * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->rows, S * H * 2);
   rc = rc ? rc : dev_alloc(e, (void**)&e->pooled, S * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->ctx_rows, S * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->mid_rows, S * I * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->preln_rows, S * H * 4);
   if (rc) {
     clip_destroy(e);
     return rc;
@@ -335,6 +339,7 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   }
   GemmArgs g;
   const int Tg = (T + 255) / 256 * 256;  // GEMM rows: whole 256-row tiles (workspace is padded)
+  const bool trim = e->trim_last && max_seqlen <= 512;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
     {
@@ -342,6 +347,7 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
       g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
       HIP_TRY(launch_gemm(g, st));
     }
+    if (trim && i == c.num_layers - 1) break;  // the rest of the last layer runs on n_seqs rows
     {
       ProfScope ps(e, CLIP_KIND_ATTENTION, st);
       HIP_TRY(launch_attention(e->qkv, cu, e->ctx, n_seqs, max_seqlen, c.num_heads, H, st));
@@ -370,8 +376,51 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
       HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st));
     }
   }
+  if (trim) {
+    // ref: sentclf/bert_model.py:52-58 / :234 consume ONE hidden row per sentence, so past the last
+    // layer's K/V projection only that row is computed: M = n_seqs instead of T.
+    const LayerW& L = e->layers[c.num_layers - 1];
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(launch_attention_focus(e->qkv, cu, focus, e->ctx_rows, n_seqs, c.num_heads, H, st));
+    }
+    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      g = GemmArgs{e->ctx_rows, L.wo, L.bo, e->rows, e->preln_rows, n_seqs, H, H, H, H, H, H, EPI_BIAS_RES, true};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(launch_layernorm(e->preln_rows, L.ln1g, L.ln1b, c.layer_norm_eps, e->rows, n_seqs, H, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      g = GemmArgs{e->rows, L.wi, L.bi, nullptr, e->mid_rows, n_seqs, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      g = GemmArgs{e->mid_rows, L.wo2, L.bo2, e->rows, e->preln_rows, n_seqs, H, I, I, I, H, H, EPI_BIAS_RES, true};
+      HIP_TRY(launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(launch_layernorm(e->preln_rows, L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
+    }
+  }
   ProfScope ps_head(e, CLIP_KIND_HEAD, st);
-  if (head_kind == 0) {
+  if (trim) {
+    if (head_kind == 0) {
+      HIP_TRY(launch_classifier(e->rows, nullptr, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
+    } else {
+      g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
+                   EPI_BIAS_TANH, false};
+      HIP_TRY(launch_gemm(g, st));
+      HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
+                                c.num_labels, st));
+    }
+  } else if (head_kind == 0) {
     HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
   } else {
     HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
@@ -381,6 +430,12 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
                               c.num_labels, st));
   }
+  return CLIP_OK;
+}
+
+int clip_set_trim_last_layer(clip_engine* e, int32_t on) {
+  if (!e) return fail(CLIP_ERR_ARG, "clip_set_trim_last_layer: null engine");
+  e->trim_last = on != 0;
   return CLIP_OK;
 }
 

@@ -27,6 +27,10 @@ hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st);
 hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
                             int max_seqlen, int n_heads, int hidden, hipStream_t st);
 
+// one q row per sequence (token index focus[s]): ctx_rows [n_seqs, H] bf16; sequences up to 512 keys
+hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
+                                  const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
+                                  int hidden, hipStream_t st);
 // out_bf16[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]])
 hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
                            const float* word, const float* pos, const float* type,

@@ -122,6 +122,12 @@ int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
                          float eps, uint16_t* dev_out, int32_t T, int32_t H, int32_t vocab,
                          int32_t max_pos, int32_t type_vocab, void* stream);
 
+/* The reference's heads read ONE hidden row per sentence (bert_model.py:52-58, :234).  With the
+ * switch on (default) the last layer computes attention, both dense blocks and both LayerNorms for
+ * that row only (M = n_seqs instead of total_tokens); off = every token through every layer, as
+ * transformers BertModel does.  Same result up to rounding (tests compare both). */
+int clip_set_trim_last_layer(clip_engine* e, int32_t on);
+
 /* HIP-event timing of the kernels inside clip_forward_packed, for bench.py's roofline figure (no
  * counterpart in the reference, which has no profiling: SURVEY.md 5).  Bit k of kind_mask turns
  * kind k on; events are recorded on the forward's stream around each launch of that kind.
@@ -130,7 +136,7 @@ int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
 enum {
   CLIP_KIND_EMBED_LN = 0, CLIP_KIND_GEMM_QKV = 1, CLIP_KIND_ATTENTION = 2,
   CLIP_KIND_GEMM_ATTN_OUT = 3, CLIP_KIND_LAYERNORM = 4, CLIP_KIND_GEMM_FFN_UP = 5,
-  CLIP_KIND_GEMM_FFN_DOWN = 6, CLIP_KIND_HEAD = 7, CLIP_N_KINDS = 8
+  CLIP_KIND_GEMM_FFN_DOWN = 6, CLIP_KIND_HEAD = 7, CLIP_KIND_LAST_LAYER_ROWS = 8, CLIP_N_KINDS = 9
 };
 int clip_profile_enable(clip_engine* e, uint32_t kind_mask);
 int clip_profile_read(clip_engine* e, double* ms_per_kind, int64_t* launches_per_kind, int32_t reset);

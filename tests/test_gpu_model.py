@@ -99,3 +99,19 @@ def test_no_cpu_path(golden):
     ids = torch.tensor([[101, 102, 102, 5, 102, 102, 102]])
     with pytest.raises(RuntimeError):
         model(input_ids=ids)
+
+
+@pytest.mark.parametrize("name", ["base_ctx", "base_sent", "tiny_ctx"])
+def test_last_layer_trim_equals_full_layers(golden, name):
+    """Computing only the pooled row past the last K/V projection (bert_model.py:52-58 consumes one
+    row per sentence) gives the same logits as pushing every token through every layer."""
+    from clip_amd import _lib
+    g = golden(name)
+    model = build_model(g)
+    trimmed, _ = run_padded(model, g)
+    _lib.check(_lib.load().clip_set_trim_last_layer(model._ensure_engine(), 0))
+    full, _ = run_padded(model, g)
+    # same arithmetic except fp32 (trimmed) vs bf16 (full) softmax weights in the last attention
+    assert np.abs(trimmed - full).max() < 3e-3
+    assert np.abs(full - g["ref_logits"]).max() < BF16_LOGIT_TOL
+    assert np.abs(trimmed - g["ref_logits"]).max() < BF16_LOGIT_TOL
