@@ -13,8 +13,8 @@
 //     every DMA it could queue behind).
 // The epilogue transposes each wave's 128x64 sub-tile through its own 8-KiB slice of staging
 // buffer 1 (idle between the last K tile and the next tile's second), buffer 0 already receives the
-// next tile.  Tile order: the 32 workgroups of an XCD (blockIdx % 8) take 32 consecutive tiles,
-// n fastest, so an A row panel and the W tiles are shared through that XCD's L2.
+// next tile.  Tile order: see the schedule comment in the kernel (XCD-owned row panels, column
+// tiles in L2-sized groups).
 #include "common.h"
 #include "kernels.h"
 
@@ -32,16 +32,43 @@ template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const bf16_t* __restrict__ res, void* __restrict__ out, int K, int lda, int ldw, int ldo,
-    int ldres, int tiles_n, int n_tiles) {
+    int ldres, int tiles_m, int tiles_n, int group_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
+  // Tile schedule.  The workgroups of one XCD (blockIdx % 8: they share an L2) walk ONE sequence,
+  // workgroup `slot` taking items slot, slot + per_x, ...  group_n > 0: the XCD owns tiles_m / 8
+  // consecutive row panels and sweeps them once per group of `group_n` column tiles, so the W
+  // slice of a group (<= 1.6 MB) stays in its 4-MiB L2 while A panels stream (PMC: the FFN-up GEMM
+  // fetched 605 MB with the plain order, W being re-fetched every round).  group_n == 0: plain
+  // order, 32 consecutive tiles (n fastest) per XCD per round.
   const int G = gridDim.x, per_x = G >> 3;
-  const int first_tile = (blockIdx.x & 7) * per_x + (blockIdx.x >> 3);
-  if (first_tile >= n_tiles) return;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_tiles = tiles_m * tiles_n;
+  const int panels = tiles_m >> 3;              // row panels per XCD (group_n > 0)
+  const int items = panels * tiles_n;      // per XCD (group_n > 0)
+  auto tile_at = [&](int i, int& tm_o, int& tn_o) -> bool {
+    if (group_n > 0) {
+      const int q = slot + per_x * i;
+      if (q >= items) return false;
+      const int per_group = panels * group_n;
+      const int g = q / per_group, r = q - g * per_group;
+      const int m = r / group_n;
+      tm_o = xcd * panels + m;
+      tn_o = g * group_n + (r - m * group_n);
+      return true;
+    }
+    const int t = i * G + xcd * per_x + slot;
+    if (t >= n_tiles) return false;
+    tm_o = t / tiles_n;
+    tn_o = t - tm_o * tiles_n;
+    return true;
+  };
+  int tm, tn;
+  if (!tile_at(0, tm, tn)) return;
 
   // DMA: piece p = 8 q + w fills LDS rows 8p .. 8p+7; the source chunk carries the swizzle
   int a_off[4], w_off[4];
@@ -69,8 +96,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(
   const int w_rd = A_BYTES + (wn * 64 + fr) * 128;
   const int nt = K / BK;
 
-  int tile = first_tile, it = 0;
-  int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int it = 0;
   const bf16_t* a_base = A + (size_t)tm * BM * lda;
   const bf16_t* w_base = W + (size_t)tn * BN * ldw;
   if (w == 0) *reinterpret_cast<float4*>(bias_lds + lane * 4) =
@@ -78,9 +104,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(
   stage(a_base, w_base, 0, 0);
 
   while (true) {
-    const int next = tile + G;
-    const bool has_next = next < n_tiles;
-    const int ntm = has_next ? next / tiles_n : 0, ntn = has_next ? next - ntm * tiles_n : 0;
+    int ntm = 0, ntn = 0;
+    const bool has_next = tile_at(it + 1, ntm, ntn);
     const bf16_t* na_base = A + (size_t)ntm * BM * lda;
     const bf16_t* nw_base = W + (size_t)ntn * BN * ldw;
     float4 nbias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(
       }
     }
     if (!has_next) break;
-    tile = next; tm = ntm; tn = ntn; a_base = na_base; w_base = nw_base;
+    tm = ntm; tn = ntn; a_base = na_base; w_base = nw_base;
     ++it;
   }
 }
@@ -239,8 +264,16 @@ hipError_t launch_p(const GemmArgs& g, hipStream_t st) {
   }
   const int tiles_m = g.M / BM, tiles_n = g.N / BN, n_tiles = tiles_m * tiles_n;
   const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
+  // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream
+  int group_n = 0;
+  if (tiles_m % 8 == 0) {
+    group_n = tiles_n;
+    if ((long)tiles_n * BN * g.K * 2 > 1700000 && g.K < 2048)
+      for (int d = 1; d <= tiles_n; ++d)
+        if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= 1700000) group_n = d;
+  }
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS_BYTES, st, g.A, g.W, g.bias, g.res, g.out, g.K,
-                     g.lda, g.ldw, g.ldo, g.ldres, tiles_n, n_tiles);
+                     g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n);
   return hipGetLastError();
 }
 

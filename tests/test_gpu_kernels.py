@@ -72,6 +72,9 @@ def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, tile):
     (40 * 256, 3072, 768, 1, False),
     (72 * 256, 768, 3072, 2, True),
     (36 * 256, 768, 768, 2, False),
+    (64 * 256, 3072, 768, 1, False),  # tiles_m % 8 == 0: XCD-owned panels, column groups of 4
+    (16 * 256, 2304, 768, 0, False),  # column groups of 3, fewer items than workgroup slots
+    (8 * 256, 768, 3072, 2, True),
 ])
 def test_persistent_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
     g = torch.Generator(device="cpu").manual_seed(M + N * 3 + K + epi)
