@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(
             float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
             float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
             if (EPI == EPI_BIAS_GELU) {
-              v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+              v0 = gelu_erf_bf16out(v0); v1 = gelu_erf_bf16out(v1); v2 = gelu_erf_bf16out(v2); v3 = gelu_erf_bf16out(v3);
             } else if (EPI == EPI_BIAS_TANH) {
               v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
             }

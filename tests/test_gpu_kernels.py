@@ -259,3 +259,20 @@ def test_bce_loss(lib):
     _sync()
     ref = torch.nn.functional.binary_cross_entropy_with_logits(x, y)
     assert abs(loss.item() - ref.item()) < 1e-6
+
+
+def test_gelu_epilogue_accuracy(lib):
+    """The bf16-output GELU epilogue uses a polynomial erf: check it against exact erf-GELU over the
+    whole input range, through a GEMM with an identity weight (so out = gelu(A + bias))."""
+    M, K = 4096, 128
+    A = torch.zeros(M, K)
+    xs = torch.linspace(-12, 12, M * K // 2)
+    A.view(-1)[::2] = xs                      # every other column, rest zero -> gelu(0) = 0 as well
+    A = A.to(torch.bfloat16).cuda()
+    W = torch.eye(K).to(torch.bfloat16).cuda()
+    bias = torch.zeros(K).cuda()
+    for tile in (128, 256):
+        out = _gemm(lib, A, W, bias, None, 1, False, tile).float()
+        ref = torch.nn.functional.gelu(A.float())
+        # polynomial error <= 6e-5 abs, then one bf16 rounding (2^-9 relative)
+        assert ((out - ref).abs() <= ref.abs() * 2 ** -8 + 1e-4).all()
