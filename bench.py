@@ -163,6 +163,14 @@ def main():
         avg_ms = ms[dominant] / max(cnt[dominant], 1)
         achieved = gemm_flops / (avg_ms * 1e-3) / 1e12
         model_flops = sum(flops_per_row(int(L), cfg) for L in batches[0]["lens"])
+        # HBM bytes per launch of the dominant kernel: from separate rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py), kept under profiles/; null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["gemm_persist_kernel<1, false>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "sentences/sec scored (whole node) BERT-base+Context seq256 bf16",
             "value": round(value, 2), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
@@ -178,7 +186,8 @@ def main():
                                              * args.steps / elapsed / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/r01_pmc_traffic.json); algorithmic operand+output bytes = %d" % (2 * T * H + 2 * I * H + 2 * T * I),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
         }
