@@ -39,6 +39,7 @@ SIGNATURES = {
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
     "clip_gemm_bf16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_gemm_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "clip_layernorm": [_p, _p, _p, _f, _p, _i32, _i32, _p],
     "clip_embed_layernorm": [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _p],

@@ -485,6 +485,15 @@ int clip_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, cons
   return CLIP_OK;
 }
 
+int clip_gemm_f32(const float* A, const float* W, const float* bias, const float* res, float* out,
+                  int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
+                  int32_t ldres, int32_t epi, void* stream) {
+  GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, true, 0, true};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
 int clip_attention_varlen(const uint16_t* qkv, const int32_t* cu, uint16_t* ctx, int32_t n_seqs,
                           int32_t max_seqlen, int32_t n_heads, int32_t hidden, void* stream) {
   if (!qkv || !cu || !ctx || n_seqs < 0) return fail(CLIP_ERR_ARG, "clip_attention_varlen: bad argument");

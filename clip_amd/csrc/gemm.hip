@@ -21,19 +21,29 @@
 
 namespace {
 
-constexpr int BK = 64;
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA, 2 no DMA in loop, 3 no epilogue stores
 #endif
 
-template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN>
+// F32IN = the fp32 check mode of the SAME kernel: operands and residual are fp32, the K tile is 32
+// elements (LDS rows stay 128 B, same swizzle, same ds_read_b128), the MFMA is the exact-fp32
+// mfma_f32_16x16x4f32 (a k-ordered fmaf chain, 1/16 of the bf16 rate).  A lane's 16-byte chunk
+// holds 4 consecutive k of its row; MFMA m of a k-step takes element m of every lane's chunk, so
+// its k set is {4 fq + m}: any order works as long as both operands use the same one.
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    const bf16_t* __restrict__ res, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
+    const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias,
+    const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
     int ldo, int ldres, int tiles_m, int tiles_n) {
+  static_assert(!F32IN || OUT_F32, "fp32 operands imply fp32 output");
+  constexpr int ESZ = F32IN ? 4 : 2;       // operand element bytes
+  constexpr int BKE = 128 / ESZ;           // K elements per tile (128-byte LDS rows)
+  const char* A = reinterpret_cast<const char*>(Av);
+  const char* W = reinterpret_cast<const char*>(Wv);
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(resv);
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF_BYTES = A_BYTES + W_BYTES;
   constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;  // 1-KiB DMA pieces per wave
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A | W]
@@ -53,27 +63,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   const int wm = w / WAVES_N, wn = w % WAVES_N;
 
   // ---- DMA source pointers: piece p = q*NW + w fills LDS rows 8p .. 8p+7 (1 KiB, lane-linear)
-  const bf16_t* a_src[A_PIECES];
-  const bf16_t* w_src[W_PIECES];
+  const char* a_src[A_PIECES];
+  const char* w_src[W_PIECES];
 #pragma unroll
   for (int q = 0; q < A_PIECES; ++q) {
     const int row = (q * NW + w) * 8 + (lane >> 3);
-    a_src[q] = A + (size_t)min(mb + row, M - 1) * lda + swz128(row, lane & 7) * 8;
+    a_src[q] = A + ((size_t)min(mb + row, M - 1) * lda) * ESZ + swz128(row, lane & 7) * 16;
   }
 #pragma unroll
   for (int q = 0; q < W_PIECES; ++q) {
     const int row = (q * NW + w) * 8 + (lane >> 3);
-    w_src[q] = W + (size_t)min(nb + row, N - 1) * ldw + swz128(row, lane & 7) * 8;
+    w_src[q] = W + ((size_t)min(nb + row, N - 1) * ldw) * ESZ + swz128(row, lane & 7) * 16;
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * BUF_BYTES;
 #pragma unroll
     for (int q = 0; q < A_PIECES; ++q)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + kt * BK),
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[q] + kt * 128),
                                        LDS_PTR(base + (q * NW + w) * 1024), 16, 0, 0);
 #pragma unroll
     for (int q = 0; q < W_PIECES; ++q)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[q] + kt * BK),
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[q] + kt * 128),
                                        LDS_PTR(base + A_BYTES + (q * NW + w) * 1024), 16, 0, 0);
   };
 
@@ -88,38 +98,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   const int a_off = (wm * TM * 16 + fr) * 128;
   const int w_off = A_BYTES + (wn * TN * 16 + fr) * 128;
 
-  const int nt = K / BK;
+  const int nt = K / BKE;
   stage(0, 0);
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t + 1 < nt && GEMM_ABLATE != 2) stage(t + 1, (t + 1) & 1);
     const char* base = smem + (t & 1) * BUF_BYTES;
-    // all 2 x (TN + TM) fragment reads of the tile are issued up front; the compiler's counted
-    // lgkmcnt waits let the first MFMAs start while the later reads are still in flight
-    bf16x8_t af[2][TM], wf[2][TN];
+    if constexpr (!F32IN) {
+      // all 2 x (TN + TM) fragment reads of the tile are issued up front; the compiler's counted
+      // lgkmcnt waits let the first MFMAs start while the later reads are still in flight
+      bf16x8_t af[2][TM], wf[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 4 + fq) ^ lsw) * 16;
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        wf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        af[ks][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 4 + fq) ^ lsw) * 16;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-          if (GEMM_ABLATE == 1) {
-            asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][j]));
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
-          }
+          wf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          af[ks][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            if (GEMM_ABLATE == 1) {
+              asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][j]));
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {  // 16 fp32 k per step = 4 MFMAs of k = 4
+        const int coff = ((ks * 4 + fq) ^ lsw) * 16;
+        f32x4_t af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          wf[i] = *reinterpret_cast<const f32x4_t*>(base + w_off + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          af[j] = *reinterpret_cast<const f32x4_t*>(base + a_off + j * 16 * 128 + coff);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][m], af[j][m], acc[i][j], 0, 0, 0);
+      }
+    }
   }
 
   // ---- epilogue.  Lane holds n = 16 i + 4 fq .. +3 of row m = 16 j + fr for every (i, j): stored
@@ -203,9 +234,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
         if (GEMM_ABLATE == 3) continue;
         if (m < M && n < N) {
           if (EPI == EPI_BIAS_RES) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n);
-            v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
-            v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+            if constexpr (F32IN) {
+              const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + (size_t)m * ldres + n);
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            } else {
+              const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n);
+              v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+              v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+            }
           }
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n) = v;
         }
@@ -214,12 +250,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN>
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-  constexpr int LDS = 2 * (BM + BN) * BK * 2;
+  constexpr int LDS = 2 * (BM + BN) * 128;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN>;
+  auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN, F32IN>;
   static bool attr_set = false;  // per instantiation; one process drives one GPU
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -246,9 +282,10 @@ hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
 
 const char* gemm_check(const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: empty problem";
-  if (g.K % BK) return "gemm: K must be a multiple of 64";
+  if (g.K % (g.f32_in ? 32 : 64)) return "gemm: K must be a multiple of 64 (32 in fp32 mode)";
+  if (g.f32_in && !g.out_f32) return "gemm: fp32 operands need an fp32 output";
   if (g.N % 16) return "gemm: N must be a multiple of 16";
-  if (g.lda % 8 || g.ldw % 8 || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
+  if (g.lda % (g.f32_in ? 4 : 8) || g.ldw % (g.f32_in ? 4 : 8) || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
   if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1) return "gemm: tile must be 0 (auto), 1 (persistent), 128 or 256";
@@ -257,6 +294,16 @@ const char* gemm_check(const GemmArgs& g) {
 }
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.f32_in) {  // fp32 check mode: 128x128 tile of the same kernel, fp32 operands
+    if (!g.out_f32) return hipErrorInvalidValue;
+    switch (g.epi) {
+      case EPI_BIAS: return launch_cfg<EPI_BIAS, true, 2, 2, 4, 4, true>(g, st);
+      case EPI_BIAS_GELU: return launch_cfg<EPI_BIAS_GELU, true, 2, 2, 4, 4, true>(g, st);
+      case EPI_BIAS_RES: return launch_cfg<EPI_BIAS_RES, true, 2, 2, 4, 4, true>(g, st);
+      case EPI_BIAS_TANH: return launch_cfg<EPI_BIAS_TANH, true, 2, 2, 4, 4, true>(g, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (g.tile == 1 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
                       !(g.epi == EPI_BIAS_TANH && g.out_f32)))
     return launch_gemm_persist(g, st);

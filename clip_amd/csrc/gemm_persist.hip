@@ -272,7 +272,8 @@ hipError_t launch_p(const GemmArgs& g, hipStream_t st) {
       for (int d = 1; d <= tiles_n; ++d)
         if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= 1700000) group_n = d;
   }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS_BYTES, st, g.A, g.W, g.bias, g.res, g.out, g.K,
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS_BYTES, st, static_cast<const bf16_t*>(g.A),
+                     static_cast<const bf16_t*>(g.W), g.bias, static_cast<const bf16_t*>(g.res), g.out, g.K,
                      g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n);
   return hipGetLastError();
 }
@@ -280,7 +281,7 @@ hipError_t launch_p(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 bool gemm_persist_ok(const GemmArgs& g) {
-  return g.M % BM == 0 && g.N % BN == 0 && g.K % (2 * BK) == 0 && g.M > 0 && g.N > 0 && g.K > 0;
+  return !g.f32_in && g.M % BM == 0 && g.N % BN == 0 && g.K % (2 * BK) == 0 && g.M > 0 && g.N > 0 && g.K > 0;
 }
 
 hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st) {

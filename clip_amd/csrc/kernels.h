@@ -5,15 +5,16 @@
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3 };
 
 struct GemmArgs {
-  const bf16_t* A;    // [M, K] activations, row stride lda (elements)
-  const bf16_t* W;    // [N, K] weight, row stride ldw
+  const void* A;      // [M, K] activations (bf16; fp32 when f32_in), row stride lda (elements)
+  const void* W;      // [N, K] weight, row stride ldw
   const float* bias;  // [N]
-  const bf16_t* res;  // [M, N] residual (EPI_BIAS_RES), row stride ldres
+  const void* res;    // [M, N] residual (EPI_BIAS_RES), row stride ldres
   void* out;          // [M, N] bf16 or f32, row stride ldo
   int M, N, K, lda, ldw, ldo, ldres;
   int epi;
   bool out_f32;
   int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip)
+  bool f32_in = false;  // fp32 check mode: fp32 operands/residual, exact-fp32 MFMA (after `tile`: positional inits)
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);

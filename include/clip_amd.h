@@ -107,6 +107,11 @@ int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* de
                    const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
                    int32_t out_f32, int32_t tile, void* stream);
+/* fp32 check mode of the same GEMM kernel: fp32 operands, residual and output, exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  K a multiple of 32. */
+int clip_gemm_f32(const float* dev_A, const float* dev_W, const float* dev_bias,
+                  const float* dev_res, float* dev_out, int32_t M, int32_t N, int32_t K,
+                  int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi, void* stream);
 /* softmax(q k^T) v per packed sequence and head (modeling_bert.py:111-136), q pre-scaled;
  * qkv bf16 [T, 3*hidden], ctx bf16 [T, hidden], head_dim 64. */
 int clip_attention_varlen(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens,

@@ -276,3 +276,29 @@ def test_gelu_epilogue_accuracy(lib):
         ref = torch.nn.functional.gelu(A.float())
         # polynomial error <= 6e-5 abs, then one bf16 rounding (2^-9 relative)
         assert ((out - ref).abs() <= ref.abs() * 2 ** -8 + 1e-4).all()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 32, 0), (300, 384, 160, 2), (515, 768, 768, 1),
+                                       (64, 3072, 768, 0), (257, 768, 3072, 2), (48, 768, 768, 3)])
+def test_gemm_fp32_check_mode(lib, M, N, K, epi):
+    """fp32 operands through the same kernel template (exact-fp32 MFMA): 1e-4-class agreement with
+    an fp64 reference — the tolerance the fp32 check mode exists for."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    W[:, 0] += torch.arange(N, device="cuda") * 0.01
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if epi == 2 else None
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.clip_gemm_f32(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
+                                 K, K, N, N if res is not None else 0, epi, _lib.stream_ptr()))
+    _sync()
+    ref = A.double() @ W.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = ref + res.double()
+    elif epi == 3:
+        ref = torch.tanh(ref)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
