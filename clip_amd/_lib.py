@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("CLIP_AMD_LIB") or os.path.join(_HERE, "lib", "libclip
 CLIP_OK, CLIP_ERR_ARG, CLIP_ERR_HIP, CLIP_ERR_STATE, CLIP_ERR_CAPACITY, CLIP_ERR_SEP_COUNT = 0, -1, -2, -3, -4, -5
 KINDS = ("embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up",
          "gemm_ffn_down", "head", "last_layer_rows")
+PRECISION_BF16, PRECISION_FP32 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH = 0, 1, 2, 3
 
 
@@ -33,6 +34,7 @@ SIGNATURES = {
     "clip_destroy": [_p],
     "clip_load_weight": [_p, C.c_char_p, _p, _i64],
     "clip_finalize_weights": [_p],
+    "clip_set_precision": [_p, _i32],
     "clip_focus_index": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
     "clip_prepare_packed": [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],

@@ -247,7 +247,112 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   ctx_rows[(size_t)seq * hidden + head * HD + lane] = f32_to_bf16(o / sum);
 }
 
+// fp32 check mode: the same softmax(q k^T) v on fp32 q/k/v with fp32 arithmetic throughout (no
+// MFMA: there is no bf16 rounding to reproduce, and check mode is not timed).  One lane per q row,
+// 128 q rows per workgroup; K/V tiles of 64 keys staged in LDS and read as wave-wide broadcasts;
+// online softmax over chunks of 16 keys.
+__global__ __launch_bounds__(128) void attention_f32_kernel(const float* __restrict__ qkv,
+                                                            const int32_t* __restrict__ cu,
+                                                            float* __restrict__ ctx, int hidden,
+                                                            int q_tiles) {
+  __shared__ __attribute__((aligned(16))) float k_s[KT * HD];
+  __shared__ __attribute__((aligned(16))) float v_s[KT * HD];
+  const int seq = blockIdx.x / q_tiles, head = blockIdx.y;
+  const int beg = cu[seq];
+  const int len = cu[seq + 1] - beg;
+  const int q_tile0 = (blockIdx.x - seq * q_tiles) * 128;
+  if (q_tile0 >= len) return;  // workgroup-uniform
+  const int tid = threadIdx.x;
+  const int ld = 3 * hidden;
+  const float* qbase = qkv + (size_t)beg * ld + head * HD;
+  const float* kbase = qbase + hidden;
+  const float* vbase = qbase + 2 * hidden;
+  const int qi = q_tile0 + tid;
+
+  float q[HD], o[HD];
+  {
+    const float4* qr = reinterpret_cast<const float4*>(qbase + (size_t)min(qi, len - 1) * ld);
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const float4 v = qr[c];
+      q[4 * c] = v.x; q[4 * c + 1] = v.y; q[4 * c + 2] = v.z; q[4 * c + 3] = v.w;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kv0 = 0; kv0 < len; kv0 += KT) {
+    __syncthreads();  // previous tile's reads done
+#pragma unroll
+    for (int i = 0; i < KT * HD / 4 / 128; ++i) {
+      const int idx = tid + 128 * i, r = idx >> 4, c = idx & 15;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (kv0 + r < len) {
+        kv = *reinterpret_cast<const float4*>(kbase + (size_t)(kv0 + r) * ld + 4 * c);
+        vv = *reinterpret_cast<const float4*>(vbase + (size_t)(kv0 + r) * ld + 4 * c);
+      }
+      *reinterpret_cast<float4*>(k_s + r * HD + 4 * c) = kv;
+      *reinterpret_cast<float4*>(v_s + r * HD + 4 * c) = vv;
+    }
+    __syncthreads();
+    const int nk = min(KT, len - kv0);
+    for (int c0 = 0; c0 < nk; c0 += 16) {  // workgroup-uniform trip count
+      float s[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4* kr = reinterpret_cast<const float4*>(k_s + (c0 + j) * HD);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+          const float4 kv = kr[c];
+          d = fmaf(q[4 * c], kv.x, d); d = fmaf(q[4 * c + 1], kv.y, d);
+          d = fmaf(q[4 * c + 2], kv.z, d); d = fmaf(q[4 * c + 3], kv.w, d);
+        }
+        s[j] = c0 + j < nk ? d : -INFINITY;
+        mx = fmaxf(mx, s[j]);
+      }
+      const float m_new = fmaxf(m_run, mx);  // finite: key c0 exists
+      const float alpha = expf(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float p = expf(s[j] - m_new);  // 0 for masked keys
+        l_run += p;
+        const float4* vr = reinterpret_cast<const float4*>(v_s + (c0 + j) * HD);
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+          const float4 vv = vr[c];
+          o[4 * c] = fmaf(p, vv.x, o[4 * c]); o[4 * c + 1] = fmaf(p, vv.y, o[4 * c + 1]);
+          o[4 * c + 2] = fmaf(p, vv.z, o[4 * c + 2]); o[4 * c + 3] = fmaf(p, vv.w, o[4 * c + 3]);
+        }
+      }
+    }
+  }
+  if (qi < len) {
+    const float inv = 1.0f / l_run;
+    float4* dst = reinterpret_cast<float4*>(ctx + (size_t)(beg + qi) * hidden + head * HD);
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c)
+      dst[c] = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, float* ctx, int n_seqs,
+                                int max_seqlen, int n_heads, int hidden, hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;
+  const int q_tiles = (max_seqlen + 127) / 128;
+  hipLaunchKernelGGL(attention_f32_kernel, dim3(q_tiles * n_seqs, n_heads), dim3(128), 0, st, qkv,
+                     cu_seqlens, ctx, hidden, q_tiles);
+  return hipGetLastError();
+}
 
 hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
                                   const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,

@@ -42,7 +42,7 @@ inline uint16_t host_f32_to_bf16(float f) {
 }
 
 struct LayerW {
-  bf16_t *wqkv, *wo, *wi, *wo2;
+  void *wqkv, *wo, *wi, *wo2;  // bf16, or fp32 in check mode
   float *bqkv, *bo, *bi, *bo2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 
@@ -57,11 +57,14 @@ struct clip_engine {
   // weights
   float *word = nullptr, *pos = nullptr, *type = nullptr, *embg = nullptr, *embb = nullptr;
   std::vector<LayerW> layers;
-  bf16_t* wpool = nullptr;
+  void* wpool = nullptr;
   float *bpool = nullptr, *wcls = nullptr, *bcls = nullptr;
-  // workspace
-  bf16_t *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
-         *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr;
+  // numerics setting of the SAME kernels (clip_set_precision): false = bf16 operands / fp32
+  // accumulation, true = fp32 check mode (fp32 weights, activations and MFMA)
+  bool f32 = false;
+  // workspace (allocated by clip_finalize_weights, element size by precision)
+  void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
+       *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr;
   float *preln = nullptr, *preln_rows = nullptr;
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
@@ -94,6 +97,43 @@ int upload_bf16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scal
   int rc = dev_alloc(e, (void**)d, n * 2);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*d, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CLIP_OK;
+}
+
+// a GEMM weight: bf16 (rounded once, here) or fp32 as loaded; the first n_first elements scaled
+int upload_w(clip_engine* e, const float* h, size_t n, void** d, float scale_first = 1.f,
+             size_t n_first = 0) {
+  if (!e->f32) return upload_bf16(e, h, n, reinterpret_cast<bf16_t**>(d), scale_first, n_first);
+  std::vector<float> tmp(h, h + n);
+  for (size_t i = 0; i < n_first; ++i) tmp[i] *= scale_first;
+  return upload_f32(e, tmp, reinterpret_cast<float**>(d));
+}
+
+int alloc_workspace(clip_engine* e) {
+  if (e->preln_rows) return CLIP_OK;  // a finalize that failed on a missing weight is retried
+  const clip_config* c = &e->cfg;
+  const size_t Tp = ((size_t)c->max_tokens + 255) / 256 * 256, H = c->hidden_size,
+               I = c->intermediate_size, S = ((size_t)c->max_seqs + 127) / 128 * 128;
+  const size_t es = e->f32 ? 4 : 2;
+  int rc = 0;
+  rc = rc ? rc : dev_alloc(e, &e->x, Tp * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->qkv, Tp * 3 * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->ctx, Tp * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->mid, Tp * I * es);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->preln, Tp * H * 4);
+  rc = rc ? rc : dev_alloc(e, &e->rows, S * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->pooled, S * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->ctx_rows, S * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->mid_rows, S * I * es);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->preln_rows, S * H * 4);
+  if (rc) return rc;
+  // rows between a call's token count and the next multiple of 256 are computed (never used) by the
+  // persistent GEMM: keep them finite from the start
+  HIP_TRY(hipMemset(e->x, 0, Tp * H * es));
+  HIP_TRY(hipMemset(e->qkv, 0, Tp * 3 * H * es));
+  HIP_TRY(hipMemset(e->ctx, 0, Tp * H * es));
+  HIP_TRY(hipMemset(e->mid, 0, Tp * I * es));
+  HIP_TRY(hipMemset(e->preln, 0, Tp * H * 4));
   return CLIP_OK;
 }
 
@@ -157,35 +197,6 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   clip_engine* e = new clip_engine();
   e->cfg = *c;
   e->device = device_id;
-  const size_t Tp = ((size_t)c->max_tokens + 255) / 256 * 256, H = c->hidden_size,
-               I = c->intermediate_size, S = ((size_t)c->max_seqs + 127) / 128 * 128;
-  int rc = 0;
-  rc = rc ? rc : dev_alloc(e, (void**)&e->x, Tp * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->qkv, Tp * 3 * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->ctx, Tp * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->mid, Tp * I * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->preln, Tp * H * 4);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->rows, S * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->pooled, S * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->ctx_rows, S * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->mid_rows, S * I * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->preln_rows, S * H * 4);
-  if (rc) {
-    clip_destroy(e);
-    return rc;
-  }
-  // rows between a call's token count and the next multiple of 256 are computed (never used) by the
-  // persistent GEMM: keep them finite from the start
-  hipError_t me = hipSuccess;
-  if (me == hipSuccess) me = hipMemset(e->x, 0, Tp * H * 2);
-  if (me == hipSuccess) me = hipMemset(e->qkv, 0, Tp * 3 * H * 2);
-  if (me == hipSuccess) me = hipMemset(e->ctx, 0, Tp * H * 2);
-  if (me == hipSuccess) me = hipMemset(e->mid, 0, Tp * I * 2);
-  if (me == hipSuccess) me = hipMemset(e->preln, 0, Tp * H * 4);
-  if (me != hipSuccess) {
-    clip_destroy(e);
-    return fail(CLIP_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(me));
-  }
   *out = e;
   return CLIP_OK;
 }
@@ -196,6 +207,16 @@ int clip_destroy(clip_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   delete e;
+  return CLIP_OK;
+}
+
+int clip_set_precision(clip_engine* e, int32_t precision) {
+  if (!e) return fail(CLIP_ERR_ARG, "clip_set_precision: null engine");
+  if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32)
+    return fail(CLIP_ERR_ARG, "clip_set_precision: unknown precision %d", precision);
+  if (e->finalized || e->preln_rows)
+    return fail(CLIP_ERR_STATE, "clip_set_precision: call before clip_finalize_weights");
+  e->f32 = precision == CLIP_PRECISION_FP32;
   return CLIP_OK;
 }
 
@@ -218,6 +239,7 @@ int clip_finalize_weights(clip_engine* e) {
   const clip_config& c = e->cfg;
   const size_t H = c.hidden_size, I = c.intermediate_size;
   int rc;
+  if ((rc = alloc_workspace(e))) return rc;
 #define GET(var, key, n)                       \
   const std::vector<float>* var = find(e, key, n); \
   if (!var) return g_err.rfind("missing", 0) == 0 ? CLIP_ERR_STATE : CLIP_ERR_ARG;
@@ -252,7 +274,7 @@ int clip_finalize_weights(clip_engine* e) {
       bqkv[H + j] = (*bk)[j];
       bqkv[2 * H + j] = (*bv)[j];
     }
-    if ((rc = upload_bf16(e, wqkv.data(), wqkv.size(), &L.wqkv, 0.125f, H * H))) return rc;
+    if ((rc = upload_w(e, wqkv.data(), wqkv.size(), &L.wqkv, 0.125f, H * H))) return rc;
     if ((rc = upload_f32(e, bqkv, &L.bqkv))) return rc;
     GET(wo, p + "attention.output.dense.weight", H * H);
     GET(bo, p + "attention.output.dense.bias", H);
@@ -264,10 +286,10 @@ int clip_finalize_weights(clip_engine* e) {
     GET(b2, p + "output.dense.bias", H);
     GET(g2, p + "output.LayerNorm.weight", H);
     GET(bb2, p + "output.LayerNorm.bias", H);
-    if ((rc = upload_bf16(e, wo->data(), wo->size(), &L.wo)) || (rc = upload_f32(e, *bo, &L.bo)) ||
+    if ((rc = upload_w(e, wo->data(), wo->size(), &L.wo)) || (rc = upload_f32(e, *bo, &L.bo)) ||
         (rc = upload_f32(e, *g1, &L.ln1g)) || (rc = upload_f32(e, *b1, &L.ln1b)) ||
-        (rc = upload_bf16(e, wi->data(), wi->size(), &L.wi)) || (rc = upload_f32(e, *bi, &L.bi)) ||
-        (rc = upload_bf16(e, w2->data(), w2->size(), &L.wo2)) || (rc = upload_f32(e, *b2, &L.bo2)) ||
+        (rc = upload_w(e, wi->data(), wi->size(), &L.wi)) || (rc = upload_f32(e, *bi, &L.bi)) ||
+        (rc = upload_w(e, w2->data(), w2->size(), &L.wo2)) || (rc = upload_f32(e, *b2, &L.bo2)) ||
         (rc = upload_f32(e, *g2, &L.ln2g)) || (rc = upload_f32(e, *bb2, &L.ln2b)))
       return rc;
   }
@@ -281,7 +303,7 @@ int clip_finalize_weights(clip_engine* e) {
     if (it != e->host_w.end() && ib != e->host_w.end()) {
       if (it->second.size() != H * H || ib->second.size() != H)
         return fail(CLIP_ERR_ARG, "pooler weight has the wrong size");
-      if ((rc = upload_bf16(e, it->second.data(), H * H, &e->wpool)) ||
+      if ((rc = upload_w(e, it->second.data(), H * H, &e->wpool)) ||
           (rc = upload_f32(e, ib->second, &e->bpool)))
         return rc;
     }
@@ -331,49 +353,57 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   const clip_config& c = e->cfg;
   const int H = c.hidden_size, I = c.intermediate_size;
 
+  const bool f32 = e->f32;
   {
     ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
     HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
-                            c.type_vocab_size, st));
+                            c.type_vocab_size, st, f32));
   }
   GemmArgs g;
-  const int Tg = (T + 255) / 256 * 256;  // GEMM rows: whole 256-row tiles (workspace is padded)
-  const bool trim = e->trim_last && max_seqlen <= 512;
+  // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
+  const int Tg = f32 ? T : (T + 255) / 256 * 256;
+  // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
+  const bool trim = e->trim_last && max_seqlen <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
     {
       ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
-      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, f32, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
     if (trim && i == c.num_layers - 1) break;  // the rest of the last layer runs on n_seqs rows
     {
       ProfScope ps(e, CLIP_KIND_ATTENTION, st);
-      HIP_TRY(launch_attention(e->qkv, cu, e->ctx, n_seqs, max_seqlen, c.num_heads, H, st));
+      if (f32)
+        HIP_TRY(launch_attention_f32(static_cast<const float*>(e->qkv), cu, static_cast<float*>(e->ctx),
+                                     n_seqs, max_seqlen, c.num_heads, H, st));
+      else
+        HIP_TRY(launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
+                                 n_seqs, max_seqlen, c.num_heads, H, st));
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, Tg, H, H, H, H, H, H, EPI_BIAS_RES, true};
+      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, Tg, H, H, H, H, H, H, EPI_BIAS_RES, true, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
     {
       ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st));
+      HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32));
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
-      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, Tg, H, I, I, I, H, H, EPI_BIAS_RES, true};
+      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, Tg, H, I, I, I, H, H, EPI_BIAS_RES, true, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
     {
       ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st));
+      HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32));
     }
   }
   if (trim) {
@@ -382,7 +412,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     const LayerW& L = e->layers[c.num_layers - 1];
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_attention_focus(e->qkv, cu, focus, e->ctx_rows, n_seqs, c.num_heads, H, st));
+      HIP_TRY(launch_attention_focus(static_cast<const bf16_t*>(e->qkv), cu, focus,
+                                     static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st));
     }
     HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
     {
@@ -421,14 +452,14 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
                                 c.num_labels, st));
     }
   } else if (head_kind == 0) {
-    HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
+    HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st, f32));
   } else {
-    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
+    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st, f32));
     g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
-                 EPI_BIAS_TANH, false};
+                 EPI_BIAS_TANH, f32, 0, f32};
     HIP_TRY(launch_gemm(g, st));
     HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
-                              c.num_labels, st));
+                              c.num_labels, st, f32));
   }
   return CLIP_OK;
 }

@@ -28,6 +28,10 @@ hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st);
 hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
                             int max_seqlen, int n_heads, int hidden, hipStream_t st);
 
+// fp32 check mode of the same attention: qkv / ctx fp32, fp32 arithmetic throughout
+hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, float* ctx, int n_seqs,
+                                int max_seqlen, int n_heads, int hidden, hipStream_t st);
+
 // one q row per sequence (token index focus[s]): ctx_rows [n_seqs, H] bf16; sequences up to 512 keys
 hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
                                   const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
@@ -35,17 +39,19 @@ hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
 // out_bf16[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]])
 hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
                            const float* word, const float* pos, const float* type,
-                           const float* gamma, const float* beta, float eps, bf16_t* out, int T,
-                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st);
+                           const float* gamma, const float* beta, float eps, void* out, int T,
+                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
+                           bool out_f32 = false);
 // out_bf16[t] = LayerNorm(x_f32[t])
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            bf16_t* out, int T, int H, hipStream_t st);
+                            void* out, int T, int H, hipStream_t st, bool out_f32 = false);
 // dst[i] = src[rows[i]]  (bf16 rows of H)
-hipError_t launch_gather_rows(const bf16_t* src, const int32_t* rows, bf16_t* dst, int n, int H,
-                              hipStream_t st);
+hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
+                              hipStream_t st, bool f32 = false);
 // logits[i] = Wc . x[rows ? rows[i] : i] + bc     (Wc [L,H] f32, x bf16)
-hipError_t launch_classifier(const bf16_t* x, const int32_t* rows, const float* Wc,
-                             const float* bc, float* logits, int n, int H, int L, hipStream_t st);
+hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,
+                             const float* bc, float* logits, int n, int H, int L, hipStream_t st,
+                             bool f32 = false);
 // focus[s] = packed token index of the (n_ctx+1)-th sep of sequence s (or of its first token when
 // n_ctx < 0: the [CLS] row); err[0] |= 1 if any sequence does not hold exactly 2*n_ctx+1 seps
 hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,

@@ -22,10 +22,13 @@ __device__ __forceinline__ void load_vec(const float* p, float* dst) {
 }
 
 // normalise the NIT*VEC values a lane holds and store them as bf16
-template <int VEC, int NIT>
+// OUT_F32 = fp32 check mode of the same kernels: the normalised row is stored as fp32
+template <int VEC, int NIT, bool OUT_F32>
 __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gamma,
-                                          const float* beta, float eps, bf16_t* out, int H,
+                                          const float* beta, float eps, void* outv, int H,
                                           int lane) {
+  bf16_t* out = reinterpret_cast<bf16_t*>(outv);
+  float* outf = reinterpret_cast<float*>(outv);
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
@@ -50,7 +53,10 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
     float y[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) y[v] = (x[it][v] - mean) * rstd * g[v] + b[v];
-    if (VEC == 4) {
+    if (OUT_F32) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) outf[e + v] = y[v];
+    } else if (VEC == 4) {
       *reinterpret_cast<uint2*>(out + e) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
     } else {
       *reinterpret_cast<uint32_t*>(out + e) = pack_bf16x2(y[0], y[1]);
@@ -58,28 +64,29 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
   }
 }
 
-template <int VEC, int NIT>
+template <int VEC, int NIT, bool OUT_F32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ xin,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        bf16_t* __restrict__ out, int T, int H) {
+                                                        void* __restrict__ out, int T, int H) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
   float x[NIT][VEC];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
-  ln_finish<VEC, NIT>(x, gamma, beta, eps, out + (size_t)row * H, H, lane);
+  ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
+                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane);
 }
 
 // BertEmbeddings.forward (transformers modeling_bert.py:68-108): word + token_type + position
-template <int VEC, int NIT>
+template <int VEC, int NIT, bool OUT_F32>
 __global__ __launch_bounds__(256) void embed_ln_kernel(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ type_ids,
     const int32_t* __restrict__ pos_ids, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    bf16_t* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab) {
+    void* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -98,22 +105,25 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) x[it][v] = (a[v] + b[v]) + c[v];
   }
-  ln_finish<VEC, NIT>(x, gamma, beta, eps, out + (size_t)row * H, H, lane);
+  ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
+                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane);
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src,
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src,
                                                           const int32_t* __restrict__ rows,
-                                                          bf16_t* __restrict__ dst, int n, int H) {
+                                                          char* __restrict__ dst, int n,
+                                                          int row_bytes) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)rows[i] * H);
-  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * H);
-  for (int c = lane; c < H / 8; c += 64) d[c] = s[c];
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)rows[i] * row_bytes);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)i * row_bytes);
+  for (int c = lane; c < row_bytes / 16; c += 64) d[c] = s[c];
 }
 
 // classifier Linear(H -> L) on one row per wave (ref: sentclf/bert_model.py:91,239)
-__global__ __launch_bounds__(256) void classifier_kernel(const bf16_t* __restrict__ x,
+template <bool F32>
+__global__ __launch_bounds__(256) void classifier_kernel(const void* __restrict__ xv,
                                                          const int32_t* __restrict__ rows,
                                                          const float* __restrict__ Wc,
                                                          const float* __restrict__ bc,
@@ -122,11 +132,17 @@ __global__ __launch_bounds__(256) void classifier_kernel(const bf16_t* __restric
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const bf16_t* xr = x + (size_t)(rows ? rows[i] : i) * H;
+  const size_t r = (size_t)(rows ? rows[i] : i) * H;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int e = lane * 2; e < H; e += 128) {
-    const uint32_t xv = *reinterpret_cast<const uint32_t*>(xr + e);
-    const float x0 = __uint_as_float(xv << 16), x1 = __uint_as_float(xv & 0xffff0000u);
+    float x0, x1;
+    if (F32) {
+      const float2 xf = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(xv) + r + e);
+      x0 = xf.x; x1 = xf.y;
+    } else {
+      const uint32_t xb = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const bf16_t*>(xv) + r + e);
+      x0 = __uint_as_float(xb << 16); x1 = __uint_as_float(xb & 0xffff0000u);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < L) {
@@ -264,56 +280,67 @@ __global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__
 }
 
 template <typename F>
-hipError_t ln_dispatch(int H, F&& f) {
+hipError_t ln_dispatch(int H, bool f32, F&& f) {
+#define LN_CASE(h, v, n) \
+  case h: return f32 ? f.template operator()<v, n, true>() : f.template operator()<v, n, false>();
   switch (H) {
-    case 128: return f.template operator()<2, 1>();
-    case 256: return f.template operator()<4, 1>();
-    case 384: return f.template operator()<2, 3>();
-    case 512: return f.template operator()<4, 2>();
-    case 768: return f.template operator()<4, 3>();
-    case 1024: return f.template operator()<4, 4>();
+    LN_CASE(128, 2, 1)
+    LN_CASE(256, 4, 1)
+    LN_CASE(384, 2, 3)
+    LN_CASE(512, 4, 2)
+    LN_CASE(768, 4, 3)
+    LN_CASE(1024, 4, 4)
     default: return hipErrorInvalidValue;
   }
+#undef LN_CASE
 }
 
 }  // namespace
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            bf16_t* out, int T, int H, hipStream_t st) {
+                            void* out, int T, int H, hipStream_t st, bool out_f32) {
   if (T <= 0) return hipSuccess;
-  return ln_dispatch(H, [&]<int VEC, int NIT>() {
-    hipLaunchKernelGGL((layernorm_kernel<VEC, NIT>), dim3((T + 3) / 4), dim3(256), 0, st, x, gamma,
-                       beta, eps, out, T, H);
+  return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
+    hipLaunchKernelGGL((layernorm_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, x,
+                       gamma, beta, eps, out, T, H);
     return hipGetLastError();
   });
 }
 
 hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
                            const float* word, const float* pos, const float* type,
-                           const float* gamma, const float* beta, float eps, bf16_t* out, int T,
-                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st) {
+                           const float* gamma, const float* beta, float eps, void* out, int T,
+                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
+                           bool out_f32) {
   if (T <= 0) return hipSuccess;
-  return ln_dispatch(H, [&]<int VEC, int NIT>() {
-    hipLaunchKernelGGL((embed_ln_kernel<VEC, NIT>), dim3((T + 3) / 4), dim3(256), 0, st, ids,
+  return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
+    hipLaunchKernelGGL((embed_ln_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, ids,
                        type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H, vocab,
                        max_pos, type_vocab);
     return hipGetLastError();
   });
 }
 
-hipError_t launch_gather_rows(const bf16_t* src, const int32_t* rows, bf16_t* dst, int n, int H,
-                              hipStream_t st) {
+hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
+                              hipStream_t st, bool f32) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, src, rows, dst, n, H);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st,
+                     reinterpret_cast<const char*>(src), rows, reinterpret_cast<char*>(dst), n,
+                     H * (f32 ? 4 : 2));
   return hipGetLastError();
 }
 
-hipError_t launch_classifier(const bf16_t* x, const int32_t* rows, const float* Wc,
-                             const float* bc, float* logits, int n, int H, int L, hipStream_t st) {
+hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,
+                             const float* bc, float* logits, int n, int H, int L, hipStream_t st,
+                             bool f32) {
   if (n <= 0) return hipSuccess;
   if (L > 8 || H % 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(classifier_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, rows, Wc, bc,
-                     logits, n, H, L);
+  if (f32)
+    hipLaunchKernelGGL(classifier_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, st, x, rows, Wc,
+                       bc, logits, n, H, L);
+  else
+    hipLaunchKernelGGL(classifier_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, st, x, rows, Wc,
+                       bc, logits, n, H, L);
   return hipGetLastError();
 }
 

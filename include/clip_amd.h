@@ -44,7 +44,8 @@ typedef struct clip_config {
 } clip_config;
 
 /* Replaces model construction + model.to(device) (apply_bert_unlabeled.py:65-72; test_load.py:21).
- * Allocates device weights and the activation workspace on `device_id`. */
+ * Binds the engine to `device_id`; device weights and the activation workspace are allocated by
+ * clip_finalize_weights. */
 int clip_create(const clip_config* cfg, int device_id, clip_engine** out);
 int clip_destroy(clip_engine* e);
 
@@ -55,6 +56,19 @@ int clip_destroy(clip_engine* e);
  * it builds the fused bf16 QKV weight (1/sqrt(head_dim) folded into the query rows). */
 int clip_load_weight(clip_engine* e, const char* name, const float* host_data, int64_t numel);
 int clip_finalize_weights(clip_engine* e);
+
+/* Numerics setting of the engine, chosen before clip_finalize_weights (which rounds the GEMM weights
+ * and sizes the activation workspace accordingly).  The reference runs fp32 torch
+ * (apply_bert_unlabeled.py:72 moves an fp32 model to the device); BASELINE.json asks for bf16 with an
+ * fp32 check mode:
+ *   CLIP_PRECISION_BF16 (default): bf16 GEMM / attention operands, fp32 accumulation, fp32
+ *     LayerNorm statistics and softmax — logits within 2e-2 of the reference;
+ *   CLIP_PRECISION_FP32: the same kernel templates instantiated on fp32 operands
+ *     (v_mfma_f32_16x16x4_f32, fp32 activations end to end; attention in plain fp32 FMAs; every layer
+ *     whole, no last-layer trimming) — logits within 1e-4 of the reference.  ~1/16 of the MFMA rate:
+ *     a checker for the bf16 path, not a production setting. */
+enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1 };
+int clip_set_precision(clip_engine* e, int32_t precision);
 
 /* Replaces _collect_focus_repr's index search (bert_model.py:52): for each packed sequence the
  * token index of its (n_ctx+1)-th `sep_id`; n_ctx < 0 selects the first token ([CLS], the pooler

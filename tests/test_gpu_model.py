@@ -116,3 +116,39 @@ def test_last_layer_trim_equals_full_layers(golden, name):
     assert np.abs(trimmed - full).max() < 6e-3
     assert np.abs(full - g["ref_logits"]).max() < BF16_LOGIT_TOL
     assert np.abs(trimmed - g["ref_logits"]).max() < BF16_LOGIT_TOL
+
+
+FP32_LOGIT_TOL = 1e-4   # BASELINE.json north_star: 1e-4 abs in the fp32 check mode
+
+
+@pytest.mark.parametrize("name", ["tiny_ctx", "tiny_ctx_n1", "tiny_sent", "base_ctx", "base_sent"])
+def test_fp32_check_mode_matches_reference(golden, name):
+    """The same kernel templates on fp32 operands (clip_set_precision): logits within 1e-4 of the
+    reference's fp32 torch forward, and every thresholded label equal unless the reference
+    probability sits within 1e-5 of its threshold."""
+    g = golden(name)
+    model = build_model(g)
+    model.set_precision("fp32")
+    logits, losses = run_padded(model, g)
+    err = np.abs(logits - g["ref_logits"]).max()
+    print(f"{name} fp32: max |logit - ref| = {err:.3e}")
+    assert err < FP32_LOGIT_TOL
+    assert np.abs(losses - g["ref_batch_loss"]).max() < 1e-5
+    p = (1 / (1 + np.exp(-logits.astype(np.float64)))).astype(np.float32)
+    for thr in (DNOTE, TTP):
+        clear = np.abs(g["ref_probs"] - thr) > 1e-5
+        assert (O.label_decisions(p, thr) == O.label_decisions(g["ref_probs"], thr))[clear].all()
+    # and the bf16 setting of the same model object stays inside its own budget of the fp32 one
+    model.set_precision("bf16")
+    bf16_logits, _ = run_padded(model, g)
+    assert np.abs(bf16_logits - logits).max() < BF16_LOGIT_TOL
+
+
+def test_precision_is_fixed_at_finalize(golden):
+    from clip_amd import _lib
+    g = golden("tiny_ctx")
+    model = build_model(g)
+    h = model._ensure_engine()
+    assert _lib.load().clip_set_precision(h, _lib.PRECISION_FP32) == _lib.CLIP_ERR_STATE
+    with pytest.raises(ValueError):
+        model.set_precision("fp16")
