@@ -288,8 +288,8 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.lda % (g.f32_in ? 4 : 8) || g.ldw % (g.f32_in ? 4 : 8) || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
-  if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1) return "gemm: tile must be 0 (auto), 1 (persistent), 128 or 256";
-  if (g.tile == 1 && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
+  if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1 && g.tile != 2) return "gemm: tile must be 0 (auto), 1 / 2 (persistent), 128 or 256";
+  if ((g.tile == 1 || g.tile == 2) && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
   return nullptr;
 }
 
@@ -304,6 +304,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
   }
+  if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
+                      !(g.epi == EPI_BIAS_TANH && g.out_f32)))
+    return launch_gemm8(g, st);
   if (g.tile == 1 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
                       !(g.epi == EPI_BIAS_TANH && g.out_f32)))
     return launch_gemm_persist(g, st);

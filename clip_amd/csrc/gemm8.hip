@@ -1,0 +1,408 @@
+// Ping-pong ("8-phase") persistent bf16 MFMA GEMM, 256x256x64 tiles, 8 waves:
+//   out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]),  M, N multiples of 256, K a multiple of 128.
+// Same math, LDS row image and epilogue fusions as gemm.hip / gemm_persist.hip (the dense layers of
+// transformers modeling_bert.py:175-177, 289-293, 334-337, 347-351 that sentclf/bert_model.py:79-88
+// runs); what changes is the schedule inside the workgroup:
+//
+//  * A K tile (64 deep) is four 16-KiB half-tiles, staged in the order A0 (A rows 0..127),
+//    B0 (W rows 0..127), B1 (W rows 128..255), A1 (A rows 128..255) into a ring of 8 slots
+//    (2 K tiles), 7 half-tiles ahead of the one being consumed, 2 LDS-DMA pieces per wave each.
+//  * A K tile is consumed in 4 phases of 16 MFMAs per wave, one 64x32 quadrant of the wave's
+//    (2 x 64) x 64 output each:  P1 reads A0,B(n-half 0)   -> acc[0][0]
+//                                P2 reads B(n-half 1)       -> acc[0][1]
+//                                P3 reads A1                -> acc[1][1]
+//                                P4 reads nothing           -> acc[1][0]   (B n-half 0 kept)
+//    so A0 is dead after P1, the B halves after P2, A1 after P3: each slot is restaged at least one
+//    phase after its last read, and every phase's ds_reads are retired (lgkmcnt(0)) BEFORE the
+//    barrier that ends its load section -> no LDS-DMA can overwrite bytes still being read.
+//  * Each phase is  [load section: ds_reads + 2 LDS-DMA pieces + waits] barrier [16 MFMAs] barrier.
+//    Waves 4..7 run one barrier behind waves 0..3 (one extra barrier at tile start, balanced by one
+//    for waves 0..3 before the epilogue), and the two waves of a SIMD are one of each group: while
+//    one issues MFMAs back to back the other does its LDS reads and DMA issue (matrix beside
+//    memory on every SIMD, MI355X_MICROARCH.md "Two waves per SIMD").
+//  * The only VM wait in the loop is a counted s_waitcnt vmcnt(6) in P4 (the three youngest
+//    half-tiles stay in flight across barriers); it retires K tile t+1 one barrier before anyone
+//    reads it.  The stream of half-tiles runs on across output tiles, so only a workgroup's first
+//    tile pays the global->LDS latency.
+//  * Epilogue as in gemm_persist.hip (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
+//    transpose, whole 128-byte row segments, non-temporal stores left in flight), through a 2-KiB
+//    scratch per wave beside the ring; the bias slice travels by LDS-DMA one tile ahead.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HT = 16384;            // half-tile: 128 rows x 128 B
+constexpr int RING = 8 * HT;         // 2 K tiles
+constexpr int SCR = 2048;            // epilogue scratch per wave
+constexpr int LDS8 = RING + 8 * SCR + 2 * 1024;  // + bias[2][256] f32
+
+#ifndef GEMM8_ABLATE
+#define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue
+#endif
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm8_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    const bf16_t* __restrict__ res, void* __restrict__ out, int K, int lda, int ldw, int ldo,
+    int ldres, int tiles_m, int tiles_n, int group_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;  // wr: barrier group AND 64-row block inside each A half
+  char* scr = smem + RING + w * SCR;
+  float* bias_lds = reinterpret_cast<float*>(smem + RING + 8 * SCR);
+
+  // ---- tile schedule (as gemm_persist.hip): the workgroups of one XCD walk one sequence
+  const int G = gridDim.x, per_x = G >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_tiles = tiles_m * tiles_n;
+  const int panels = tiles_m >> 3;
+  const int items = panels * tiles_n;
+  auto tile_at = [&](int i, int& tm_o, int& tn_o) -> bool {
+    if (group_n > 0) {
+      const int q = slot + per_x * i;
+      if (q >= items) return false;
+      const int per_group = panels * group_n;
+      const int g = q / per_group, r = q - g * per_group;
+      const int m = r / group_n;
+      tm_o = xcd * panels + m;
+      tn_o = g * group_n + (r - m * group_n);
+      return true;
+    }
+    const int t = i * G + xcd * per_x + slot;
+    if (t >= n_tiles) return false;
+    tm_o = t / tiles_n;
+    tn_o = t - tm_o * tiles_n;
+    return true;
+  };
+  int tm, tn;
+  if (!tile_at(0, tm, tn)) return;  // workgroup-uniform
+
+  // ---- LDS-DMA: this wave's two 1-KiB pieces of a half-tile = rows 8w..8w+7 and 64+8w..64+8w+7;
+  // the source chunk carries the swizzle (the image the DMA writes is lane-linear)
+  const int prow = w * 8 + (lane >> 3);
+  const int pchunk = swz128(prow, lane & 7) * 8;
+  const int a_off = prow * lda + pchunk, w_off = prow * ldw + pchunk;
+  auto stage_half = [&](const bf16_t* src, int off, int ld, int slot_idx) {
+    char* dst = smem + slot_idx * HT + w * 1024;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src + off), LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src + off + 64 * ld), LDS_PTR(dst + 8192), 16, 0, 0);
+  };
+  auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slice: uniform counts
+    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + lane * 4),
+                                     LDS_PTR(reinterpret_cast<char*>(bias_lds) + buf * 1024), 16, 0, 0);
+  };
+
+  const int nt = K / BK;  // even
+  // staging cursors: K tile t+1 (c1) and t+2 (c2) of the flattened (tile, k) stream
+  const bf16_t *a1, *w1, *a2, *w2;
+  bool v1, v2;
+  int s_it = 0, s_kt = 0, s_tm = tm, s_tn = tn;  // position of c2
+  auto advance = [&]() {  // c1 <- c2, c2 <- the K tile after c2
+    a1 = a2; w1 = w2; v1 = v2;
+    if (!v2) return;
+    if (++s_kt == nt) {
+      s_kt = 0;
+      ++s_it;
+      v2 = tile_at(s_it, s_tm, s_tn);
+      if (!v2) return;
+    }
+    a2 = A + (size_t)s_tm * BM * lda + s_kt * BK;
+    w2 = W + (size_t)s_tn * BN * ldw + s_kt * BK;
+  };
+
+  // ---- prologue: K tile 0 whole, the bias slice, three half-tiles of K tile 1
+  {
+    const bf16_t* a0 = A + (size_t)tm * BM * lda;
+    const bf16_t* w0 = W + (size_t)tn * BN * ldw;
+    stage_half(a0, a_off, lda, 0);
+    stage_half(w0, w_off, ldw, 1);
+    stage_half(w0 + (size_t)128 * ldw, w_off, ldw, 2);
+    stage_half(a0 + (size_t)128 * lda, a_off, lda, 3);
+    stage_bias(tn, 0);
+    a2 = a0; w2 = w0; v2 = true;
+    advance();  // c2 = K tile 1
+    advance();  // c1 = K tile 1, c2 = K tile 2 (or the next tile's first)
+    stage_half(a1, a_off, lda, 4);
+    stage_half(w1, w_off, ldw, 5);
+    stage_half(w1 + (size_t)128 * ldw, w_off, ldw, 6);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int lsw = (fr >> 1) & 7;
+  const int a_rd = (wr * 64 + fr) * 128;                                  // within an A half-tile
+  const int b_rd = (1 + (wc >> 1)) * HT + ((wc & 1) * 64 + fr) * 128;     // B half slot + row
+  const int c0 = (fq ^ lsw) * 16, c1 = ((4 + fq) ^ lsw) * 16;             // chunk of k-step 0 / 1
+
+  int it = 0;
+  while (true) {
+    int ntm = 0, ntn = 0;
+    const bool has_next = tile_at(it + 1, ntm, ntn);
+
+    // acc[mh][nh][m][i]: lane holds n = 4 fq .. +3 of 16-col block (nh, i), row fr of 16-row block
+    // (mh, m).  The bias is added after the K loop, as the other GEMM kernels do: a row's result
+    // is bit-identical whichever kernel (i.e. whichever batch size) computed it.
+    f32x4_t acc[2][2][4][2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[mh][nh][m][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4..7 run one barrier behind
+
+    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    for (int kk = 0; kk < nt; kk += 2) {
+      auto ktile = [&]<int B>() {
+        const char* buf = smem + B * 4 * HT;
+        // ---------------- P1: A0, B n-half 0 -> acc[0][0]; stage (t+1).A1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf0[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c0);
+          bf0[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c1);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c1);
+        }
+        if (B == 1 && kk == 0 && has_next) stage_bias(ntn, (it + 1) & 1);
+        if (v1) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[0][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[0][0][m][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P2: B n-half 1 -> acc[0][1]; stage (t+2).A0
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf1[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c0);
+          bf1[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
+        }
+        if (v2) stage_half(a2, a_off, lda, B * 4 + 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[0][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[0][1][m][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P3: A1 -> acc[1][1]; stage (t+2).B0
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
+        }
+        if (v2) stage_half(w2, w_off, ldw, B * 4 + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[1][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[1][1][m][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- P4: -> acc[1][0]; stage (t+2).B1; K tile t+1 retired one barrier early
+        if (v2) {
+          stage_half(w2 + (size_t)128 * ldw, w_off, ldw, B * 4 + 2);
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[1][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[1][0][m][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        advance();
+      };
+      ktile.template operator()<0>();
+      ktile.template operator()<1>();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balances the extra barrier of waves 4..7
+
+    // ---- epilogue: 16-row passes through this wave's scratch, whole 128-byte row segments out
+    const int n_base = tn * BN + wc * 64;
+    f32x4_t bv[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        bv[nh][i] = *reinterpret_cast<const f32x4_t*>(bias_lds + (it & 1) * BN + wc * 64 + fq * 4 + nh * 32 + i * 16);
+    if (GEMM8_ABLATE == 1) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(acc[mh][nh][m][i]));
+    } else if (!OUT_F32) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          // image [16 rows][128 B]; 8-byte slots XOR-swizzled in pairs so the 16-B reads stay whole
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              float v0 = acc[mh][nh][m][i][0] + bv[nh][i][0], v1 = acc[mh][nh][m][i][1] + bv[nh][i][1];
+              float v2f = acc[mh][nh][m][i][2] + bv[nh][i][2], v3 = acc[mh][nh][m][i][3] + bv[nh][i][3];
+              if (EPI == EPI_BIAS_GELU) {
+                v0 = gelu_erf_bf16out(v0); v1 = gelu_erf_bf16out(v1); v2f = gelu_erf_bf16out(v2f); v3 = gelu_erf_bf16out(v3);
+              } else if (EPI == EPI_BIAS_TANH) {
+                v0 = tanhf(v0); v1 = tanhf(v1); v2f = tanhf(v2f); v3 = tanhf(v3);
+              }
+              const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
+              *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
+                  make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2f, v3));
+            }
+          const size_t m0 = (size_t)tm * BM + mh * 128 + wr * 64 + m * 16;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+            const size_t mg = m0 + row;
+            const int n = n_base + c16 * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
+            if (EPI == EPI_BIAS_RES) {
+              const uint4 r = *reinterpret_cast<const uint4*>(res + mg * ldres + n);
+              const uint32_t* vi = reinterpret_cast<const uint32_t*>(&v);
+              const uint32_t* ri = reinterpret_cast<const uint32_t*>(&r);
+              uint32_t o[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                o[k] = pack_bf16x2(__uint_as_float(vi[k] << 16) + __uint_as_float(ri[k] << 16),
+                                   __uint_as_float(vi[k] & 0xffff0000u) + __uint_as_float(ri[k] & 0xffff0000u));
+              v = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            __builtin_nontemporal_store(*reinterpret_cast<u32x4_t*>(&v),
+                                        reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(out) + mg * ldo + n));
+          }
+        }
+    } else {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            // image [16 rows][32 f32 = 128 B], 16-byte slots XOR-swizzled by row
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              float v0 = acc[mh][nh][m][i][0] + bv[nh][i][0], v1 = acc[mh][nh][m][i][1] + bv[nh][i][1];
+              float v2f = acc[mh][nh][m][i][2] + bv[nh][i][2], v3 = acc[mh][nh][m][i][3] + bv[nh][i][3];
+              if (EPI == EPI_BIAS_GELU) {
+                v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2f = gelu_erf(v2f); v3 = gelu_erf(v3);
+              } else if (EPI == EPI_BIAS_TANH) {
+                v0 = tanhf(v0); v1 = tanhf(v1); v2f = tanhf(v2f); v3 = tanhf(v3);
+              }
+              *reinterpret_cast<float4*>(scr + fr * 128 + (((i * 4 + fq) ^ (fr & 7)) * 16)) =
+                  make_float4(v0, v1, v2f, v3);
+            }
+            const size_t m0 = (size_t)tm * BM + mh * 128 + wr * 64 + m * 16;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+              const size_t mg = m0 + row;
+              const int n = n_base + nh * 32 + c16 * 4;
+              float4 v = *reinterpret_cast<const float4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
+              if (EPI == EPI_BIAS_RES) {
+                const uint2 rv = *reinterpret_cast<const uint2*>(res + mg * ldres + n);
+                v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+                v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+              }
+              __builtin_nontemporal_store(*reinterpret_cast<f32x4_t*>(&v),
+                                          reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + mg * ldo + n));
+            }
+          }
+    }
+    if (!has_next) break;
+    tm = ntm; tn = ntn;
+    ++it;
+  }
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
+  auto kfn = gemm8_kernel<EPI, OUT_F32>;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    n_cu = cus & ~7;
+    if (n_cu < 8) return hipErrorInvalidValue;
+  }
+  const int tiles_m = g.M / BM, tiles_n = g.N / BN, n_tiles = tiles_m * tiles_n;
+  const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
+  // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream
+  int group_n = 0;
+  if (tiles_m % 8 == 0) {
+    group_n = tiles_n;
+    if ((long)tiles_n * BN * g.K * 2 > 1700000 && g.K < 2048)
+      for (int d = 1; d <= tiles_n; ++d)
+        if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= 1700000) group_n = d;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS8, st, static_cast<const bf16_t*>(g.A),
+                     static_cast<const bf16_t*>(g.W), g.bias, static_cast<const bf16_t*>(g.res), g.out, g.K,
+                     g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
+  if (!gemm_persist_ok(g)) return hipErrorInvalidValue;
+  switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
+    case EPI_BIAS * 2 + 0: return launch_8<EPI_BIAS, false>(g, st);
+    case EPI_BIAS * 2 + 1: return launch_8<EPI_BIAS, true>(g, st);
+    case EPI_BIAS_GELU * 2 + 0: return launch_8<EPI_BIAS_GELU, false>(g, st);
+    case EPI_BIAS_RES * 2 + 1: return launch_8<EPI_BIAS_RES, true>(g, st);
+    case EPI_BIAS_RES * 2 + 0: return launch_8<EPI_BIAS_RES, false>(g, st);
+    case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
+    default: return hipErrorInvalidValue;
+  }
+}

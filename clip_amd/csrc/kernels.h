@@ -13,13 +13,14 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres;
   int epi;
   bool out_f32;
-  int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip)
+  int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip); 2: ping-pong persistent (gemm8.hip)
   bool f32_in = false;  // fp32 check mode: fp32 operands/residual, exact-fp32 MFMA (after `tile`: positional inits)
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 bool gemm_persist_ok(const GemmArgs& g);
 hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st);
+hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st);  // ping-pong schedule (gemm8.hip), same shapes
 
 // varlen self-attention over packed sequences; qkv [T, 3H] bf16 (q | k | v, heads of 64),
 // q pre-scaled by 1/sqrt(64); ctx [T, H] bf16. One workgroup per (128-row q tile, sequence, head).

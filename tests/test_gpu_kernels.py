@@ -76,14 +76,15 @@ def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, tile):
     (16 * 256, 2304, 768, 0, False),  # column groups of 3, fewer items than workgroup slots
     (8 * 256, 768, 3072, 2, True),
 ])
-def test_persistent_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
+@pytest.mark.parametrize("kind", [1, 2])   # 1: persistent, 2: ping-pong persistent (gemm8.hip)
+def test_persistent_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, kind):
     g = torch.Generator(device="cpu").manual_seed(M + N * 3 + K + epi)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
     W[:, 0] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.01
     bias = torch.randn(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
-    out = _gemm(lib, A, W, bias, res, epi, out_f32, 1).float()
+    out = _gemm(lib, A, W, bias, res, epi, out_f32, kind).float()
     ref = A.float() @ W.float().T + bias
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
@@ -93,10 +94,12 @@ def test_persistent_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32):
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < tol
     # run-to-run determinism (a race in the DMA / barrier protocol shows up as flicker)
-    out2 = _gemm(lib, A, W, bias, res, epi, out_f32, 1).float()
-    assert torch.equal(out, out2)
-    # and identical to the one-tile-per-workgroup kernel: same MFMA order per output element
+    for _ in range(3):
+        out2 = _gemm(lib, A, W, bias, res, epi, out_f32, kind).float()
+        assert torch.equal(out, out2)
     out3 = _gemm(lib, A, W, bias, res, epi, out_f32, 256).float()
+    # identical to the one-tile-per-workgroup kernel: same MFMA order per output element, so a row's
+    # result does not depend on which kernel (= which batch size) computed it
     assert torch.equal(out, out3)
 
 

@@ -9,7 +9,7 @@ lib = _lib.load()
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 2, True), ("ffn_up", 3072, 768, 1, False),
           ("ffn_down", 768, 3072, 2, True)]
-tiles = [int(t) for t in os.environ.get("TILES", "256,1").split(",")]
+tiles = [int(t) for t in os.environ.get("TILES", "1,2").split(",")]
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, N, K, epi, f32 in shapes:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
