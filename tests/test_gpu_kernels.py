@@ -277,8 +277,8 @@ def test_gelu_epilogue_accuracy(lib):
     for tile in (128, 256):
         out = _gemm(lib, A, W, bias, None, 1, False, tile).float()
         ref = torch.nn.functional.gelu(A.float())
-        # polynomial error <= 6e-5 abs, then one bf16 rounding (2^-9 relative)
-        assert ((out - ref).abs() <= ref.abs() * 2 ** -8 + 1e-4).all()
+        # polynomial error <= 1.46e-4 abs, then one bf16 rounding (2^-9 relative)
+        assert ((out - ref).abs() <= ref.abs() * 2 ** -8 + 2e-4).all()
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(128, 128, 32, 0), (300, 384, 160, 2), (515, 768, 768, 1),

@@ -1,36 +1,62 @@
-"""A/B the GEMM tile shapes on the encoder's four projection shapes (interleaved rounds in one
-process, random data; guide rule 24/25). Usage: python tools/gemm_bench.py [M]"""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from clip_amd import _lib
+"""A/B GEMM kernels / builds on the encoder's four projection shapes (interleaved rounds in one
+process, random data; guide rules 24/25).
 
-lib = _lib.load()
+    python tools/gemm_bench.py [M]
+    VARIANTS="base:1,base:2,noepi:2" python tools/gemm_bench.py     # lib:tile pairs
+
+`base` is the product library; any other name is gpurun_tmp/lib<name>.so (tools/build_variant.sh).
+tile: 1 persistent, 2 ping-pong persistent, 128 / 256 one tile per workgroup."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from clip_amd import _lib  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+variants = [v.split(":") for v in os.environ.get("VARIANTS", "base:1,base:2").split(",")]
+libs = {}
+for name, _ in variants:
+    if name in libs:
+        continue
+    if name == "base":
+        libs[name] = _lib.load()
+    else:
+        lib = C.CDLL(os.path.join(ROOT, "gpurun_tmp", f"lib{name}.so"))
+        lib.clip_gemm_bf16.argtypes = _lib.SIGNATURES["clip_gemm_bf16"]
+        lib.clip_gemm_bf16.restype = C.c_int
+        libs[name] = lib
 shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 2, True), ("ffn_up", 3072, 768, 1, False),
           ("ffn_down", 768, 3072, 2, True)]
-tiles = [int(t) for t in os.environ.get("TILES", "1,2").split(",")]
 g = torch.Generator(device="cpu").manual_seed(0)
-for name, N, K, epi, f32 in shapes:
+for sname, N, K, epi, f32 in shapes:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).cuda()
     bias = torch.randn(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
     out = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
-    def run(tile):
-        _lib.check(lib.clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
-                                      K, K, N, N if res is not None else 0, epi, int(f32), tile, _lib.stream_ptr()))
-    best = {t: 1e9 for t in tiles}
-    for t in tiles:
-        run(t)
+
+    def run(v):
+        rc = libs[v[0]].clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
+                                       K, K, N, N if res is not None else 0, epi, int(f32), int(v[1]),
+                                       _lib.stream_ptr())
+        assert rc == 0, rc
+    keys = [":".join(v) for v in variants]
+    best = {k: 1e9 for k in keys}
+    for v in variants:
+        run(v)
     torch.cuda.synchronize()
     for rnd in range(5):
-        for t in tiles:
+        for v, k in zip(variants, keys):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                run(t)
-            e1.record(); torch.cuda.synchronize()
-            best[t] = min(best[t], e0.elapsed_time(e1) / 10)
+                run(v)
+            e1.record()
+            torch.cuda.synchronize()
+            best[k] = min(best[k], e0.elapsed_time(e1) / 10)
     fl = 2.0 * M * N * K
-    print(name, f"M={M} N={N} K={K}", "  ".join(f"tile{t}: {best[t]*1e3:.1f} us {fl/best[t]/1e9:.0f} TF" for t in tiles), flush=True)
+    print(sname, f"M={M} N={N} K={K}", "  ".join(f"{k}: {best[k]*1e3:.1f} us {fl/best[k]/1e9:.0f} TF" for k in keys),
+          flush=True)
