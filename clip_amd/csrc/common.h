@@ -37,6 +37,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm of one element from its row statistics.  One definition for the LayerNorm kernels and
+// for the GEMM epilogues that RE-compute the fp32 LayerNorm output as their residual operand
+// (EPI_BIAS_LNRES): the residual stream then never passes through a bf16 rounding.
+__device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float g, float b) {
+  return fmaf((x - mean) * rstd, g, b);
+}
+
 // erf-GELU as torch's nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // below fp32 resolution of the surrounding sum and ~5x cheaper than libm erff in a GEMM epilogue).
 __device__ __forceinline__ float erf_as(float x) {

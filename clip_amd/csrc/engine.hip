@@ -65,7 +65,10 @@ struct clip_engine {
   // workspace (allocated by clip_finalize_weights, element size by precision)
   void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
        *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr;
-  float *preln = nullptr, *preln_rows = nullptr;
+  // fp32 pre-LayerNorm rows and their (mean, rstd), double-buffered: a GEMM writes pre[b ^ 1] while
+  // its epilogue re-derives the residual from pre[b] / stats[b] (EPI_BIAS_LNRES)
+  float *pre[2] = {nullptr, nullptr}, *stats[2] = {nullptr, nullptr};
+  float *pre_rows[2] = {nullptr, nullptr}, *stats_rows[2] = {nullptr, nullptr};
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -110,7 +113,7 @@ int upload_w(clip_engine* e, const float* h, size_t n, void** d, float scale_fir
 }
 
 int alloc_workspace(clip_engine* e) {
-  if (e->preln_rows) return CLIP_OK;  // a finalize that failed on a missing weight is retried
+  if (e->stats_rows[1]) return CLIP_OK;  // a finalize that failed on a missing weight is retried
   const clip_config* c = &e->cfg;
   const size_t Tp = ((size_t)c->max_tokens + 255) / 256 * 256, H = c->hidden_size,
                I = c->intermediate_size, S = ((size_t)c->max_seqs + 127) / 128 * 128;
@@ -120,12 +123,16 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, &e->qkv, Tp * 3 * H * es);
   rc = rc ? rc : dev_alloc(e, &e->ctx, Tp * H * es);
   rc = rc ? rc : dev_alloc(e, &e->mid, Tp * I * es);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->preln, Tp * H * 4);
+  for (int b = 0; b < 2; ++b) {
+    rc = rc ? rc : dev_alloc(e, (void**)&e->pre[b], Tp * H * 4);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->stats[b], Tp * 8);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->pre_rows[b], S * H * 4);
+  }
   rc = rc ? rc : dev_alloc(e, &e->rows, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->pooled, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->ctx_rows, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->mid_rows, S * I * es);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->preln_rows, S * H * 4);
+  for (int b = 0; b < 2; ++b) rc = rc ? rc : dev_alloc(e, (void**)&e->stats_rows[b], S * 8);
   if (rc) return rc;
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
   // persistent GEMM: keep them finite from the start
@@ -133,7 +140,10 @@ int alloc_workspace(clip_engine* e) {
   HIP_TRY(hipMemset(e->qkv, 0, Tp * 3 * H * es));
   HIP_TRY(hipMemset(e->ctx, 0, Tp * H * es));
   HIP_TRY(hipMemset(e->mid, 0, Tp * I * es));
-  HIP_TRY(hipMemset(e->preln, 0, Tp * H * 4));
+  for (int b = 0; b < 2; ++b) {
+    HIP_TRY(hipMemset(e->pre[b], 0, Tp * H * 4));
+    HIP_TRY(hipMemset(e->stats[b], 0, Tp * 8));
+  }
   return CLIP_OK;
 }
 
@@ -214,7 +224,7 @@ int clip_set_precision(clip_engine* e, int32_t precision) {
   if (!e) return fail(CLIP_ERR_ARG, "clip_set_precision: null engine");
   if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32)
     return fail(CLIP_ERR_ARG, "clip_set_precision: unknown precision %d", precision);
-  if (e->finalized || e->preln_rows)
+  if (e->finalized || e->stats_rows[1])
     return fail(CLIP_ERR_STATE, "clip_set_precision: call before clip_finalize_weights");
   e->f32 = precision == CLIP_PRECISION_FP32;
   return CLIP_OK;
@@ -354,11 +364,25 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   const int H = c.hidden_size, I = c.intermediate_size;
 
   const bool f32 = e->f32;
+  // Residual operands.  bf16 setting: the GEMM epilogue re-derives the fp32 LayerNorm output from the
+  // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
+  // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
+  // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
+  int cur = 0;
+  const float *g_prev = e->embg, *b_prev = e->embb;
+  auto res_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* pre_in,
+                      const float* stats_in, float* pre_out, const int32_t* index) {
+    GemmArgs a{A, W, bias, f32 ? e->x : (const void*)pre_in, pre_out, M, H, K, K, K, H, H,
+               f32 ? EPI_BIAS_RES : EPI_BIAS_LNRES, true, 0, f32};
+    if (!f32) { a.ln_stats = stats_in; a.ln_gamma = g_prev; a.ln_beta = b_prev; a.res_index = index; }
+    return launch_gemm(a, st);
+  };
   {
     ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
     HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
-                            c.type_vocab_size, st, f32));
+                            c.type_vocab_size, st, f32, f32 ? nullptr : e->pre[0],
+                            f32 ? nullptr : e->stats[0]));
   }
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
@@ -384,13 +408,15 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      g = GemmArgs{e->ctx, L.wo, L.bo, e->x, e->preln, Tg, H, H, H, H, H, H, EPI_BIAS_RES, true, 0, f32};
-      HIP_TRY(launch_gemm(g, st));
+      HIP_TRY(res_gemm(e->ctx, L.wo, L.bo, Tg, H, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
     }
+    cur ^= 1;
     {
       ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->preln, L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32));
+      HIP_TRY(launch_layernorm(e->pre[cur], L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32,
+                               f32 ? nullptr : e->stats[cur]));
     }
+    g_prev = L.ln1g; b_prev = L.ln1b;
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
       g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
@@ -398,13 +424,15 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      g = GemmArgs{e->mid, L.wo2, L.bo2, e->x, e->preln, Tg, H, I, I, I, H, H, EPI_BIAS_RES, true, 0, f32};
-      HIP_TRY(launch_gemm(g, st));
+      HIP_TRY(res_gemm(e->mid, L.wo2, L.bo2, Tg, I, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
     }
+    cur ^= 1;
     {
       ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->preln, L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32));
+      HIP_TRY(launch_layernorm(e->pre[cur], L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32,
+                               f32 ? nullptr : e->stats[cur]));
     }
+    g_prev = L.ln2g; b_prev = L.ln2b;
   }
   if (trim) {
     // ref: sentclf/bert_model.py:52-58 / :234 consume ONE hidden row per sentence, so past the last
@@ -415,16 +443,16 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
       HIP_TRY(launch_attention_focus(static_cast<const bf16_t*>(e->qkv), cu, focus,
                                      static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st));
     }
-    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st));
     {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      g = GemmArgs{e->ctx_rows, L.wo, L.bo, e->rows, e->preln_rows, n_seqs, H, H, H, H, H, H, EPI_BIAS_RES, true};
-      HIP_TRY(launch_gemm(g, st));
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
+      HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_layernorm(e->preln_rows, L.ln1g, L.ln1b, c.layer_norm_eps, e->rows, n_seqs, H, st));
+      HIP_TRY(launch_layernorm(e->pre_rows[0], L.ln1g, L.ln1b, c.layer_norm_eps, e->rows, n_seqs, H, st,
+                               false, e->stats_rows[0]));
     }
+    g_prev = L.ln1g; b_prev = L.ln1b;
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
       g = GemmArgs{e->rows, L.wi, L.bi, nullptr, e->mid_rows, n_seqs, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
@@ -432,12 +460,11 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      g = GemmArgs{e->mid_rows, L.wo2, L.bo2, e->rows, e->preln_rows, n_seqs, H, I, I, I, H, H, EPI_BIAS_RES, true};
-      HIP_TRY(launch_gemm(g, st));
+      HIP_TRY(res_gemm(e->mid_rows, L.wo2, L.bo2, n_seqs, I, e->pre_rows[0], e->stats_rows[0], e->pre_rows[1], nullptr));
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_layernorm(e->preln_rows, L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
+      HIP_TRY(launch_layernorm(e->pre_rows[1], L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
     }
   }
   ProfScope ps_head(e, CLIP_KIND_HEAD, st);
@@ -516,6 +543,20 @@ int clip_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, cons
   return CLIP_OK;
 }
 
+int clip_gemm_bf16_lnres(const uint16_t* A, const uint16_t* W, const float* bias, const float* res_pre,
+                         const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                         const int32_t* res_index, float* out, int32_t M, int32_t N, int32_t K,
+                         int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t tile,
+                         void* stream) {
+  GemmArgs g{A, W, bias, res_pre, out, M, N, K, lda, ldw, ldo, ldres, EPI_BIAS_LNRES, true, tile};
+  g.ln_stats = ln_stats; g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.res_index = res_index;
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  if (res_index && (tile == 1 || tile == 2)) return fail(CLIP_ERR_ARG, "gemm: res_index needs a one-tile kernel");
+  if (tile == 1) return fail(CLIP_ERR_ARG, "gemm: the LayerNorm-residual epilogue is not built for tile 1");
+  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
 int clip_gemm_f32(const float* A, const float* W, const float* bias, const float* res, float* out,
                   int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
                   int32_t ldres, int32_t epi, void* stream) {
@@ -536,6 +577,14 @@ int clip_layernorm(const float* x, const float* gamma, const float* beta, float 
                    int32_t T, int32_t H, void* stream) {
   if (!x || !gamma || !beta || !out || T < 0) return fail(CLIP_ERR_ARG, "clip_layernorm: bad argument");
   HIP_TRY(launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps,
+                         uint16_t* out, float* stats, int32_t T, int32_t H, void* stream) {
+  if (!x || !gamma || !beta || !out || !stats || T < 0)
+    return fail(CLIP_ERR_ARG, "clip_layernorm_stats: bad argument");
+  HIP_TRY(launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream, false, stats));
   return CLIP_OK;
 }
 

@@ -34,7 +34,9 @@ template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool 
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
-    int ldo, int ldres, int tiles_m, int tiles_n) {
+    int ldo, int ldres, int tiles_m, int tiles_n, const float2* __restrict__ ln_stats,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
+    const int32_t* __restrict__ res_index) {
   static_assert(!F32IN || OUT_F32, "fp32 operands imply fp32 output");
   constexpr int ESZ = F32IN ? 4 : 2;       // operand element bytes
   constexpr int BKE = 128 / ESZ;           // K elements per tile (128-byte LDS rows)
@@ -233,6 +235,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
         float4 v = *reinterpret_cast<const float4*>(ep + row * 256 + ((c16 ^ (row & 15)) * 16));
         if (GEMM_ABLATE == 3) continue;
         if (m < M && n < N) {
+          if (EPI == EPI_BIAS_LNRES) {
+            const int rr = res_index ? res_index[m] : m;
+            const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + (size_t)rr * ldres + n);
+            const float2 sv = ln_stats[rr];
+            const float4 gv = *reinterpret_cast<const float4*>(ln_gamma + n);
+            const float4 be = *reinterpret_cast<const float4*>(ln_beta + n);
+            v.x += ln_apply(rv.x, sv.x, sv.y, gv.x, be.x); v.y += ln_apply(rv.y, sv.x, sv.y, gv.y, be.y);
+            v.z += ln_apply(rv.z, sv.x, sv.y, gv.z, be.z); v.w += ln_apply(rv.w, sv.x, sv.y, gv.w, be.w);
+          }
           if (EPI == EPI_BIAS_RES) {
             if constexpr (F32IN) {
               const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + (size_t)m * ldres + n);
@@ -265,7 +276,8 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   }
   hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n), dim3(64 * WAVES_M * WAVES_N), LDS, st, g.A, g.W,
                      g.bias, g.res, g.out, g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldres, tiles_m,
-                     tiles_n);
+                     tiles_n, reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta,
+                     g.res_index);
   return hipGetLastError();
 }
 
@@ -287,6 +299,9 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.N % 16) return "gemm: N must be a multiple of 16";
   if (g.lda % (g.f32_in ? 4 : 8) || g.ldw % (g.f32_in ? 4 : 8) || g.ldo % 4) return "gemm: leading dimensions must keep 16-byte rows";
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
+  if (g.epi == EPI_BIAS_LNRES && (!g.res || g.ldres % 4 || !g.ln_stats || !g.ln_gamma || !g.ln_beta || !g.out_f32 || g.f32_in))
+    return "gemm: LayerNorm-residual epilogue needs fp32 pre-LN rows, statistics, gamma, beta and an fp32 output";
+  if (g.res_index && g.epi != EPI_BIAS_LNRES) return "gemm: res_index only with the LayerNorm-residual epilogue";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
   if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1 && g.tile != 2) return "gemm: tile must be 0 (auto), 1 / 2 (persistent), 128 or 256";
   if ((g.tile == 1 || g.tile == 2) && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
@@ -304,12 +319,11 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
   }
+  if (g.res_index && (g.tile == 1 || g.tile == 2)) return hipErrorInvalidValue;
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
-                      !(g.epi == EPI_BIAS_TANH && g.out_f32)))
+                      !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index))
     return launch_gemm8(g, st);
-  if (g.tile == 1 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
-                      !(g.epi == EPI_BIAS_TANH && g.out_f32)))
-    return launch_gemm_persist(g, st);
+  if (g.tile == 1) return launch_gemm_persist(g, st);
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_one<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_one<EPI_BIAS, true>(g, st);
@@ -318,6 +332,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_RES * 2 + 0: return launch_one<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_one<EPI_BIAS_TANH, false>(g, st);
     case EPI_BIAS_TANH * 2 + 1: return launch_one<EPI_BIAS_TANH, true>(g, st);
+    case EPI_BIAS_LNRES * 2 + 1: return launch_one<EPI_BIAS_LNRES, true>(g, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -37,7 +37,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HT = 16384;            // half-tile: 128 rows x 128 B
 constexpr int RING = 8 * HT;         // 2 K tiles
 constexpr int SCR = 2048;            // epilogue scratch per wave
-constexpr int LDS8 = RING + 8 * SCR + 2 * 1024;  // + bias[2][256] f32
+constexpr int LDS8 = RING + 8 * SCR + 2 * 3072;  // + {bias, ln gamma, ln beta}[2][256] f32
 
 #ifndef GEMM8_ABLATE
 #define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue
@@ -46,9 +46,11 @@ constexpr int LDS8 = RING + 8 * SCR + 2 * 1024;  // + bias[2][256] f32
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-    const bf16_t* __restrict__ res, void* __restrict__ out, int K, int lda, int ldw, int ldo,
-    int ldres, int tiles_m, int tiles_n, int group_n) {
+    const void* __restrict__ resv, void* __restrict__ out, int K, int lda, int ldw, int ldo,
+    int ldres, int tiles_m, int tiles_n, int group_n, const float2* __restrict__ ln_stats,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bf16_t* res = reinterpret_cast<const bf16_t*>(resv);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,9 +94,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     __builtin_amdgcn_global_load_lds(GLB_PTR(src + off), LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(GLB_PTR(src + off + 64 * ld), LDS_PTR(dst + 8192), 16, 0, 0);
   };
-  auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slice: uniform counts
-    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + lane * 4),
-                                     LDS_PTR(reinterpret_cast<char*>(bias_lds) + buf * 1024), 16, 0, 0);
+  auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slices: uniform counts
+    char* dst = reinterpret_cast<char*>(bias_lds) + buf * 3072;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + lane * 4), LDS_PTR(dst), 16, 0, 0);
+    if (EPI == EPI_BIAS_LNRES) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_gamma + tn_x * BN + lane * 4), LDS_PTR(dst + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_beta + tn_x * BN + lane * 4), LDS_PTR(dst + 2048), 16, 0, 0);
+    }
   };
 
   const int nt = K / BK;  // even
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        bv[nh][i] = *reinterpret_cast<const f32x4_t*>(bias_lds + (it & 1) * BN + wc * 64 + fq * 4 + nh * 32 + i * 16);
+        bv[nh][i] = *reinterpret_cast<const f32x4_t*>(bias_lds + (it & 1) * 768 + wc * 64 + fq * 4 + nh * 32 + i * 16);
     if (GEMM8_ABLATE == 1) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
@@ -350,6 +356,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                 const uint2 rv = *reinterpret_cast<const uint2*>(res + mg * ldres + n);
                 v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
                 v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+              } else if (EPI == EPI_BIAS_LNRES) {
+                const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + mg * ldres + n);
+                const float2 sv = ln_stats[mg];
+                const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + nh * 32 + c16 * 4;
+                const float4 gv = *reinterpret_cast<const float4*>(gl);
+                const float4 be = *reinterpret_cast<const float4*>(gl + 256);
+                v.x += ln_apply(rv.x, sv.x, sv.y, gv.x, be.x); v.y += ln_apply(rv.y, sv.x, sv.y, gv.y, be.y);
+                v.z += ln_apply(rv.z, sv.x, sv.y, gv.z, be.z); v.w += ln_apply(rv.w, sv.x, sv.y, gv.w, be.w);
               }
               __builtin_nontemporal_store(*reinterpret_cast<f32x4_t*>(&v),
                                           reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + mg * ldo + n));
@@ -387,15 +401,16 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
         if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= 1700000) group_n = d;
   }
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS8, st, static_cast<const bf16_t*>(g.A),
-                     static_cast<const bf16_t*>(g.W), g.bias, static_cast<const bf16_t*>(g.res), g.out, g.K,
-                     g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n);
+                     static_cast<const bf16_t*>(g.W), g.bias, g.res, g.out, g.K,
+                     g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n,
+                     reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
-  if (!gemm_persist_ok(g)) return hipErrorInvalidValue;
+  if (!gemm_persist_ok(g) || g.res_index) return hipErrorInvalidValue;
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_8<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_8<EPI_BIAS, true>(g, st);
@@ -403,6 +418,7 @@ hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_RES * 2 + 1: return launch_8<EPI_BIAS_RES, true>(g, st);
     case EPI_BIAS_RES * 2 + 0: return launch_8<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
+    case EPI_BIAS_LNRES * 2 + 1: return launch_8<EPI_BIAS_LNRES, true>(g, st);
     default: return hipErrorInvalidValue;
   }
 }

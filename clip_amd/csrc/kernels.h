@@ -2,7 +2,10 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3 };
+// EPI_BIAS_LNRES: out_f32 = A W^T + bias + LayerNorm(pre)[m, n], the residual operand recomputed in
+// fp32 from the producer's pre-LayerNorm row (`res` = pre, fp32), its row statistics and affine —
+// what the reference adds is the fp32 LayerNorm output (modeling_bert.py:292,350), not a bf16 copy.
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3, EPI_BIAS_LNRES = 4 };
 
 struct GemmArgs {
   const void* A;      // [M, K] activations (bf16; fp32 when f32_in), row stride lda (elements)
@@ -15,6 +18,11 @@ struct GemmArgs {
   bool out_f32;
   int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip); 2: ping-pong persistent (gemm8.hip)
   bool f32_in = false;  // fp32 check mode: fp32 operands/residual, exact-fp32 MFMA (after `tile`: positional inits)
+  // EPI_BIAS_LNRES: res = fp32 pre-LayerNorm rows [., N] (row stride ldres), and:
+  const float* ln_stats = nullptr;   // [rows] (mean, rstd) pairs
+  const float* ln_gamma = nullptr;   // [N]
+  const float* ln_beta = nullptr;    // [N]
+  const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
@@ -42,10 +50,11 @@ hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const in
                            const float* word, const float* pos, const float* type,
                            const float* gamma, const float* beta, float eps, void* out, int T,
                            int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
-                           bool out_f32 = false);
+                           bool out_f32 = false, float* pre_out = nullptr, float* stats = nullptr);
 // out_bf16[t] = LayerNorm(x_f32[t])
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            void* out, int T, int H, hipStream_t st, bool out_f32 = false);
+                            void* out, int T, int H, hipStream_t st, bool out_f32 = false,
+                            float* stats = nullptr);  // stats: optional [T] (mean, rstd) pairs out
 // dst[i] = src[rows[i]]  (bf16 rows of H)
 hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
                               hipStream_t st, bool f32 = false);

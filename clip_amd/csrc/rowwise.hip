@@ -26,7 +26,7 @@ __device__ __forceinline__ void load_vec(const float* p, float* dst) {
 template <int VEC, int NIT, bool OUT_F32>
 __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gamma,
                                           const float* beta, float eps, void* outv, int H,
-                                          int lane) {
+                                          int lane, float2* stats_row) {
   bf16_t* out = reinterpret_cast<bf16_t*>(outv);
   float* outf = reinterpret_cast<float*>(outv);
   float s = 0.f;
@@ -44,6 +44,7 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
       q += d * d;
     }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  if (stats_row && lane == 0) *stats_row = make_float2(mean, rstd);  // for EPI_BIAS_LNRES consumers
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = (it * 64 + lane) * VEC;
@@ -52,7 +53,7 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
     load_vec<VEC>(beta + e, b);
     float y[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) y[v] = (x[it][v] - mean) * rstd * g[v] + b[v];
+    for (int v = 0; v < VEC; ++v) y[v] = ln_apply(x[it][v], mean, rstd, g[v], b[v]);
     if (OUT_F32) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) outf[e + v] = y[v];
@@ -68,7 +69,8 @@ template <int VEC, int NIT, bool OUT_F32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ xin,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        void* __restrict__ out, int T, int H) {
+                                                        void* __restrict__ out, int T, int H,
+                                                        float2* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
   ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
-                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane);
+                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane,
+                               stats ? stats + row : nullptr);
 }
 
 // BertEmbeddings.forward (transformers modeling_bert.py:68-108): word + token_type + position
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
     const int32_t* __restrict__ pos_ids, const float* __restrict__ word,
     const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    void* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab) {
+    void* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab,
+    float* __restrict__ pre_out, float2* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -104,9 +108,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
     load_vec<VEC>(pos + (size_t)po * H + e, c);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) x[it][v] = (a[v] + b[v]) + c[v];
+    if (pre_out) {  // the un-normalised sum, for the first layer's recomputed residual
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) pre_out[(size_t)row * H + e + v] = x[it][v];
+    }
   }
   ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
-                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane);
+                               reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane,
+                               stats ? stats + row : nullptr);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src,
@@ -298,11 +307,11 @@ hipError_t ln_dispatch(int H, bool f32, F&& f) {
 }  // namespace
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            void* out, int T, int H, hipStream_t st, bool out_f32) {
+                            void* out, int T, int H, hipStream_t st, bool out_f32, float* stats) {
   if (T <= 0) return hipSuccess;
   return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
     hipLaunchKernelGGL((layernorm_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, x,
-                       gamma, beta, eps, out, T, H);
+                       gamma, beta, eps, out, T, H, reinterpret_cast<float2*>(stats));
     return hipGetLastError();
   });
 }
@@ -311,12 +320,12 @@ hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const in
                            const float* word, const float* pos, const float* type,
                            const float* gamma, const float* beta, float eps, void* out, int T,
                            int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
-                           bool out_f32) {
+                           bool out_f32, float* pre_out, float* stats) {
   if (T <= 0) return hipSuccess;
   return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
     hipLaunchKernelGGL((embed_ln_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, ids,
                        type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H, vocab,
-                       max_pos, type_vocab);
+                       max_pos, type_vocab, pre_out, reinterpret_cast<float2*>(stats));
     return hipGetLastError();
   });
 }

@@ -116,11 +116,23 @@ int clip_bce_loss(const float* dev_logits, const float* dev_targets, int32_t cou
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias): epi 0 bias, 1 bias+erf-GELU, 2 bias+residual, 3 bias+tanh
  * (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463). A, W, res are bf16; out bf16 or
  * fp32 (out_f32). Leading dimensions in elements. tile: 0 = choose, 128 / 256 = force that
- * workgroup tile edge. */
+ * workgroup tile edge, 1 / 2 = persistent / ping-pong persistent (M, N multiples of 256, K of 128). */
 int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
                    const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
                    int32_t out_f32, int32_t tile, void* stream);
+/* The residual form the engine uses in the bf16 setting: out_f32[m,n] = A W^T + bias + LN(pre)[r,n]
+ * with r = res_index ? res_index[m] : m, where LN(pre) is the fp32 LayerNorm output
+ * (modeling_bert.py:292,350: what the reference adds as the residual) recomputed in the epilogue from
+ * the producer's fp32 pre-LayerNorm rows `dev_res_pre`, their (mean, rstd) pairs `dev_ln_stats`
+ * (clip_layernorm_stats) and the affine — so the residual stream never passes through bf16.
+ * tile as clip_gemm_bf16 except 1; res_index only with the one-tile kernels (0, 128, 256). */
+int clip_gemm_bf16_lnres(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                         const float* dev_res_pre, const float* dev_ln_stats,
+                         const float* dev_ln_gamma, const float* dev_ln_beta,
+                         const int32_t* dev_res_index, float* dev_out, int32_t M, int32_t N,
+                         int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres,
+                         int32_t tile, void* stream);
 /* fp32 check mode of the same GEMM kernel: fp32 operands, residual and output, exact-fp32 MFMA
  * (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  K a multiple of 32. */
 int clip_gemm_f32(const float* dev_A, const float* dev_W, const float* dev_bias,
@@ -134,6 +146,9 @@ int clip_attention_varlen(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens
 /* out_bf16[t] = LayerNorm(x_f32[t]) (modeling_bert.py:292,350) */
 int clip_layernorm(const float* dev_x, const float* dev_gamma, const float* dev_beta, float eps,
                    uint16_t* dev_out, int32_t T, int32_t H, void* stream);
+/* the same, also writing dev_stats[t] = (mean, rstd) for clip_gemm_bf16_lnres consumers */
+int clip_layernorm_stats(const float* dev_x, const float* dev_gamma, const float* dev_beta, float eps,
+                         uint16_t* dev_out, float* dev_stats, int32_t T, int32_t H, void* stream);
 /* BertEmbeddings.forward (modeling_bert.py:68-108): tables fp32, out bf16 [T,H] */
 int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
                          const int32_t* dev_pos_ids, const float* dev_word, const float* dev_pos,

@@ -305,3 +305,69 @@ def test_gemm_fp32_check_mode(lib, M, N, K, epi):
         ref = torch.tanh(ref)
     err = (out.double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def _ln_ref(pre, gamma, beta, eps=1e-12):
+    mu = pre.mean(-1, keepdim=True)
+    var = ((pre - mu) ** 2).mean(-1, keepdim=True)
+    return (pre - mu) / torch.sqrt(var + eps) * gamma + beta, mu.squeeze(-1), (1 / torch.sqrt(var + eps)).squeeze(-1)
+
+
+def test_layernorm_stats(lib):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T, H = 1000, 768
+    x = (torch.randn(T, H, generator=g) * 2 + 0.3).cuda()
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).cuda()
+    beta = (0.1 * torch.randn(H, generator=g)).cuda()
+    out = torch.empty(T, H, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(T, 2, device="cuda")
+    _lib.check(lib.clip_layernorm_stats(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(out),
+                                        _lib.ptr(stats), T, H, _lib.stream_ptr()))
+    _sync()
+    ref, mu, rstd = _ln_ref(x.double(), gamma.double(), beta.double())
+    assert (stats[:, 0].double() - mu).abs().max().item() < 1e-6
+    assert ((stats[:, 1].double() - rstd) / rstd).abs().max().item() < 1e-6
+    assert (out.double() - ref).abs().max().item() < 2 ** -8 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,tile,indexed", [
+    (64 * 256, 768, 768, 2, False),    # ping-pong persistent, XCD-owned panels
+    (36 * 256, 768, 3072, 2, False),   # tiles_m % 8 != 0: plain tile order
+    (300, 768, 768, 0, False),         # one-tile kernel, ragged M
+    (77, 768, 3072, 0, True),          # residual rows picked by index (trimmed last layer)
+])
+def test_gemm_layernorm_residual_epilogue(lib, M, N, K, tile, indexed):
+    """out = A W^T + bias + LN(pre): the residual is the fp32 LayerNorm output recomputed from the
+    pre-LN rows, their (mean, rstd) and the affine — compared with an fp64 reference, and bit for bit
+    between the ping-pong kernel and the one-tile kernel (batch-size invariance of a row's result)."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = M if not indexed else 1000
+    pre = (torch.randn(R, N, generator=g) * 1.5 + 0.2).cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    idx = torch.randint(0, R, (M,), generator=g).to(torch.int32).cuda() if indexed else None
+    xb = torch.empty(R, N, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(R, 2, device="cuda")
+    _lib.check(lib.clip_layernorm_stats(_lib.ptr(pre), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(xb),
+                                        _lib.ptr(stats), R, N, _lib.stream_ptr()))
+
+    def run(t):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.clip_gemm_bf16_lnres(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(pre), _lib.ptr(stats),
+                                            _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(idx), _lib.ptr(out), M, N, K,
+                                            K, K, N, N, t, _lib.stream_ptr()))
+        _sync()
+        return out
+    out = run(tile)
+    lnref, _, _ = _ln_ref(pre.double(), gamma.double(), beta.double())
+    if indexed:
+        lnref = lnref[idx.long()]
+    ref = A.double() @ W.double().T + bias.double() + lnref
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 2e-3
+    if tile == 2:
+        assert torch.equal(out, run(256))
+        assert torch.equal(out, run(2))
