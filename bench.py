@@ -167,8 +167,8 @@ def main():
         # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py), kept under profiles/; null if absent
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["gemm_persist_kernel<1, false>"]["hbm_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["gemm8_kernel<1, false>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -184,10 +184,10 @@ def main():
             "model_tflops_per_gpu": round(model_flops * args.steps / elapsed / 1e12, 2),
             "executed_tflops_per_gpu": round((model_flops - sum(flops_saved_per_row(int(L), cfg) for L in batches[0]["lens"]))
                                              * args.steps / elapsed / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_persist_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
+            "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/r01_pmc_traffic.json); algorithmic operand+output bytes = %d" % (2 * T * H + 2 * I * H + 2 * T * I),
+                         "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/r01_v8_pmc_traffic.json); algorithmic operand+output bytes = %d" % (2 * T * H + 2 * I * H + 2 * T * I),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
         }

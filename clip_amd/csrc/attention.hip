@@ -97,40 +97,49 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     if (!wave_live) continue;
 
     const int kv0 = t * KT;
-    // ---- S^T = K Q^T for the two 32-key blocks
+    // ---- S^T = K Q^T for the two 32-key blocks (first k-step accumulates onto an inline 0)
     f32x16_t s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
       const int row = kb * 32 + l31;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
             k_lds + row * 128 + swz128(row, 2 * ks + h) * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        if (ks == 0) {
+          const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], zero, 0, 0, 0);
+        } else {
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
       }
     }
-    // ---- mask keys past the end, tile max
-    float mx = -INFINITY;
+    // ---- keys past the end exist only in the last tile (wave-uniform test): mask there only
+    if (kv0 + KT > len) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = key < len ? s[kb][r] * LOG2E : -INFINITY;
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s[kb][r] = key < len ? s[kb][r] : -INFINITY;
+        }
+    }
+    // ---- tile max on the raw scores (v_max3), then into the log2 domain
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * LOG2E);  // finite: every tile holds at least one valid key
+    // the running max moves in the first tile or two and then rarely: rescale only when some row's did
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 1 exactly where the max stayed
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     m_run = m_new;
-    l_run *= alpha;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
 
     // ---- P = exp2(S - m), O^T += V^T P^T
 #pragma unroll
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = exp2f(s[kb][r] - m_new);
+        p[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -m_new));  // v_exp_f32: inputs <= 0
         l_run += p[r];
       }
 #pragma unroll

@@ -1,0 +1,53 @@
+"""A/B attention kernel builds (interleaved rounds, one process, random data).
+    VARIANTS="base,vgpr" python tools/attn_bench.py [L] [n_seqs]     # names = gpurun_tmp/lib<name>.so"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from clip_amd import _lib  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536 // L
+H, nh = 768, 12
+names = os.environ.get("VARIANTS", "base").split(",")
+libs = {}
+for name in names:
+    if name == "base":
+        libs[name] = _lib.load()
+    else:
+        lib = C.CDLL(os.path.join(ROOT, "gpurun_tmp", f"lib{name}.so"))
+        lib.clip_attention_varlen.argtypes = _lib.SIGNATURES["clip_attention_varlen"]
+        lib.clip_attention_varlen.restype = C.c_int
+        libs[name] = lib
+g = torch.Generator(device="cpu").manual_seed(0)
+qkv = torch.randn(n * L, 3 * H, generator=g).to(torch.bfloat16).cuda()
+cu = (torch.arange(n + 1, dtype=torch.int32) * L).cuda()
+ctx = torch.empty(n * L, H, dtype=torch.bfloat16, device="cuda")
+outs = {}
+
+
+def run(name):
+    rc = libs[name].clip_attention_varlen(_lib.ptr(qkv), _lib.ptr(cu), _lib.ptr(ctx), n, L, nh, H, _lib.stream_ptr())
+    assert rc == 0
+
+
+best = {k: 1e9 for k in names}
+for k in names:
+    run(k)
+    torch.cuda.synchronize()
+    outs[k] = ctx.float().clone()
+for rnd in range(5):
+    for k in names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run(k)
+        e1.record()
+        torch.cuda.synchronize()
+        best[k] = min(best[k], e0.elapsed_time(e1) / 10)
+fl = 4.0 * n * L * L * H
+print(f"L={L} n={n}", "  ".join(f"{k}: {best[k]*1e3:.1f} us {fl/best[k]/1e9:.0f} TF" for k in names),
+      " max|diff vs first| " + " ".join(f"{(outs[k]-outs[names[0]]).abs().max().item():.2e}" for k in names), flush=True)

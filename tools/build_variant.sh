@@ -8,7 +8,8 @@ name=$1; shift
 out=../../gpurun_tmp/lib$name.so
 mkdir -p ../../gpurun_tmp/obj_$name
 for f in gemm gemm_persist gemm8 attention rowwise engine; do
-  /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $f.hip -o ../../gpurun_tmp/obj_$name/$f.o &
+  extra=""; [ $f = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"   # as the Makefile
+  /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -c $f.hip -o ../../gpurun_tmp/obj_$name/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out ../../gpurun_tmp/obj_$name/*.o

@@ -5,7 +5,7 @@ so fetch is doubled; WRITE_SIZE is exact for 16-B stores.  Usage:
     python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json"""
 import collections, csv, json, re, sys
 
-PAT = re.compile(r"(gemm_persist_kernel<\d, \w+>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
+PAT = re.compile(r"(gemm8_kernel<\d, \w+>|gemm_persist_kernel<\d, \w+>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
                  r"layernorm_kernel|embed_ln_kernel)")
 
 
