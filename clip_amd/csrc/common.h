@@ -94,6 +94,24 @@ __device__ __forceinline__ float gelu_erf_bf16out(float x) {
   return x * fmaf(xc, q, 0.5f);
 }
 
+// The same polynomial on two values at a time with packed fp32 math (v_pk_mul_f32 / v_pk_fma_f32):
+// 2 clamps + 9 packed ops per pair instead of 20.  Bit-identical to gelu_erf_bf16out per element.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ f32x2_t gelu_erf_bf16out_x2(f32x2_t x) {
+  f32x2_t xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -3.9f, 3.9f);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -3.9f, 3.9f);
+  const f32x2_t u = xc * xc;
+  auto c = [](float v) { return (f32x2_t){v, v}; };
+  f32x2_t q = __builtin_elementwise_fma(c(2.627150074e-08f), u, c(-1.770499288e-06f));
+  q = __builtin_elementwise_fma(q, u, c(5.123743311e-05f));
+  q = __builtin_elementwise_fma(q, u, c(-8.445144153e-04f));
+  q = __builtin_elementwise_fma(q, u, c(8.913803536e-03f));
+  q = __builtin_elementwise_fma(q, u, c(-6.486952130e-02f));
+  q = __builtin_elementwise_fma(q, u, c(3.980856433e-01f));
+  return x * __builtin_elementwise_fma(xc, q, c(0.5f));
+}
+
 // 16-byte chunk swizzle for LDS tiles with 128-byte rows (8 chunks per row): conflict-free for
 // the ds_read_b128 operand reads of both the 16x16x32 and the 32x32x16 MFMA.
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }

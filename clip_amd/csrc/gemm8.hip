@@ -6,24 +6,24 @@
 //
 //  * A K tile (64 deep) is four 16-KiB half-tiles, staged in the order A0 (A rows 0..127),
 //    B0 (W rows 0..127), B1 (W rows 128..255), A1 (A rows 128..255) into a ring of 8 slots
-//    (2 K tiles), 7 half-tiles ahead of the one being consumed, 2 LDS-DMA pieces per wave each.
-//  * A K tile is consumed in 4 phases of 16 MFMAs per wave, one 64x32 quadrant of the wave's
-//    (2 x 64) x 64 output each:  P1 reads A0,B(n-half 0)   -> acc[0][0]
-//                                P2 reads B(n-half 1)       -> acc[0][1]
-//                                P3 reads A1                -> acc[1][1]
-//                                P4 reads nothing           -> acc[1][0]   (B n-half 0 kept)
-//    so A0 is dead after P1, the B halves after P2, A1 after P3: each slot is restaged at least one
-//    phase after its last read, and every phase's ds_reads are retired (lgkmcnt(0)) BEFORE the
+//    (2 K tiles), 4..6 half-tiles ahead of the one being consumed, 2 LDS-DMA pieces per wave each.
+//  * A K tile is consumed in 2 phases of 32 MFMAs per wave, one 64x64 half of the wave's
+//    (2 x 64) x 64 output each:  phase A reads A0 and both B n-halves -> acc[0][*]
+//                                phase B reads A1 (B fragments kept)  -> acc[1][*]
+//    so A0 and the B halves are dead after phase A, A1 after phase B: each slot is restaged at least
+//    one phase after its last read, and every phase's ds_reads are retired (lgkmcnt(0)) BEFORE the
 //    barrier that ends its load section -> no LDS-DMA can overwrite bytes still being read.
-//  * Each phase is  [load section: ds_reads + 2 LDS-DMA pieces + waits] barrier [16 MFMAs] barrier.
+//    (GEMM8_PH == 4 builds the finer schedule this grew from: 4 phases of 16 MFMAs, 7 half-tiles
+//    ahead, one counted vmcnt(6) per K tile; 4..9 % slower in the main loop.)
+//  * Each phase is  [load section: ds_reads + 4 LDS-DMA pieces + waits] barrier [32 MFMAs] barrier.
 //    Waves 4..7 run one barrier behind waves 0..3 (one extra barrier at tile start, balanced by one
 //    for waves 0..3 before the epilogue), and the two waves of a SIMD are one of each group: while
 //    one issues MFMAs back to back the other does its LDS reads and DMA issue (matrix beside
 //    memory on every SIMD, MI355X_MICROARCH.md "Two waves per SIMD").
-//  * The only VM wait in the loop is a counted s_waitcnt vmcnt(6) in P4 (the three youngest
-//    half-tiles stay in flight across barriers); it retires K tile t+1 one barrier before anyone
-//    reads it.  The stream of half-tiles runs on across output tiles, so only a workgroup's first
-//    tile pays the global->LDS latency.
+//  * Phase A stages (t+1).B1 and (t+1).A1, phase B stages (t+2).A0 and (t+2).B0; the VM waits are
+//    counted (vmcnt(8) / vmcnt(4)): two half-tiles, or four, stay in flight across barriers, and
+//    what a phase reads was retired one barrier earlier.  The stream of half-tiles runs on across
+//    output tiles, so only a workgroup's first tile pays the global->LDS latency.
 //  * Epilogue as in gemm_persist.hip (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
 //    transpose, whole 128-byte row segments, non-temporal stores left in flight), through a 2-KiB
 //    scratch per wave beside the ring; the bias slice travels by LDS-DMA one tile ahead.
@@ -42,6 +42,17 @@ constexpr int LDS8 = RING + 8 * SCR + 2 * 3072;  // + {bias, ln gamma, ln beta}[
 #ifndef GEMM8_ABLATE
 #define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue
 #endif
+#ifndef GEMM8_PH
+#define GEMM8_PH 2      // phases per K tile: 2 (32 MFMAs between barriers; main loop +4..9 %) or 4 (16)
+#endif
+#ifndef GEMM8_STORE
+#define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
+#endif
+template <typename V>
+__device__ __forceinline__ void out_store(V v, V* p) {
+  if (GEMM8_STORE == 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 template <int EPI, bool OUT_F32>
 __global__ __launch_bounds__(512) void gemm8_kernel(
@@ -135,8 +146,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     advance();  // c1 = K tile 1, c2 = K tile 2 (or the next tile's first)
     stage_half(a1, a_off, lda, 4);
     stage_half(w1, w_off, ldw, 5);
+#if GEMM8_PH == 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
     stage_half(w1 + (size_t)128 * ldw, w_off, ldw, 6);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
   }
 
@@ -167,6 +182,84 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
     for (int kk = 0; kk < nt; kk += 2) {
+#if GEMM8_PH == 2
+      auto ktile = [&]<int B>() {
+        const char* buf = smem + B * 4 * HT;
+        // ---------------- phase A: A0, both B n-halves -> acc[0][*]; stage (t+1).B1, (t+1).A1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf0[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c0);
+          bf0[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c1);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf1[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c0);
+          bf1[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
+        }
+        if (v1) {
+          stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
+          stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+          // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
+          // (t).A1, read next phase, is older
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // younger than everything the wait above covers, older than phase B's DMA: retired by B's wait
+        if (B == 1 && kk == 0 && has_next) stage_bias(ntn, (it + 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[0][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[0][0][m][i], 0, 0, 0);
+              acc[0][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[0][1][m][i], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase B: A1 -> acc[1][*]; stage (t+2).A0, (t+2).B0; K tile t+1 retired
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
+        }
+        if (v2) {
+          stage_half(a2, a_off, lda, B * 4 + 0);
+          stage_half(w2, w_off, ldw, B * 4 + 1);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[1][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[1][1][m][i], 0, 0, 0);
+              acc[1][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[1][0][m][i], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        advance();
+      };
+#else
       auto ktile = [&]<int B>() {
         const char* buf = smem + B * 4 * HT;
         // ---------------- P1: A0, B n-half 0 -> acc[0][0]; stage (t+1).A1
@@ -260,6 +353,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         __builtin_amdgcn_s_barrier();
         advance();
       };
+#endif
       ktile.template operator()<0>();
       ktile.template operator()<1>();
     }
@@ -295,7 +389,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               float v0 = acc[mh][nh][m][i][0] + bv[nh][i][0], v1 = acc[mh][nh][m][i][1] + bv[nh][i][1];
               float v2f = acc[mh][nh][m][i][2] + bv[nh][i][2], v3 = acc[mh][nh][m][i][3] + bv[nh][i][3];
               if (EPI == EPI_BIAS_GELU) {
-                v0 = gelu_erf_bf16out(v0); v1 = gelu_erf_bf16out(v1); v2f = gelu_erf_bf16out(v2f); v3 = gelu_erf_bf16out(v3);
+                // packed fp32 math: same bits per element as gelu_erf_bf16out, 296 -> 285 us on FFN-up
+                const f32x2_t g01 = gelu_erf_bf16out_x2((f32x2_t){v0, v1}), g23 = gelu_erf_bf16out_x2((f32x2_t){v2f, v3});
+                v0 = g01[0]; v1 = g01[1]; v2f = g23[0]; v3 = g23[1];
               } else if (EPI == EPI_BIAS_TANH) {
                 v0 = tanhf(v0); v1 = tanhf(v1); v2f = tanhf(v2f); v3 = tanhf(v3);
               }
@@ -321,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                                    __uint_as_float(vi[k] & 0xffff0000u) + __uint_as_float(ri[k] & 0xffff0000u));
               v = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            __builtin_nontemporal_store(*reinterpret_cast<u32x4_t*>(&v),
+            out_store(*reinterpret_cast<u32x4_t*>(&v),
                                         reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(out) + mg * ldo + n));
           }
         }
@@ -365,7 +461,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                 v.x += ln_apply(rv.x, sv.x, sv.y, gv.x, be.x); v.y += ln_apply(rv.y, sv.x, sv.y, gv.y, be.y);
                 v.z += ln_apply(rv.z, sv.x, sv.y, gv.z, be.z); v.w += ln_apply(rv.w, sv.x, sv.y, gv.w, be.w);
               }
-              __builtin_nontemporal_store(*reinterpret_cast<f32x4_t*>(&v),
+              out_store(*reinterpret_cast<f32x4_t*>(&v),
                                           reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(out) + mg * ldo + n));
             }
           }

@@ -27,9 +27,12 @@ for name, _ in variants:
         lib = C.CDLL(os.path.join(ROOT, "gpurun_tmp", f"lib{name}.so"))
         lib.clip_gemm_bf16.argtypes = _lib.SIGNATURES["clip_gemm_bf16"]
         lib.clip_gemm_bf16.restype = C.c_int
+        lib.clip_gemm_bf16_lnres.argtypes = _lib.SIGNATURES["clip_gemm_bf16_lnres"]
+        lib.clip_gemm_bf16_lnres.restype = C.c_int
         libs[name] = lib
-shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 2, True), ("ffn_up", 3072, 768, 1, False),
-          ("ffn_down", 768, 3072, 2, True)]
+# epi 4 = the engine's residual form (fp32 LayerNorm output recomputed in the epilogue)
+shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 4, True), ("ffn_up", 3072, 768, 1, False),
+          ("ffn_down", 768, 3072, 4, True)]
 g = torch.Generator(device="cpu").manual_seed(0)
 for sname, N, K, epi, f32 in shapes:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
@@ -37,8 +40,18 @@ for sname, N, K, epi, f32 in shapes:
     bias = torch.randn(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
     out = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+    if epi == 4:
+        pre = torch.randn(M, N, generator=g).cuda()
+        stats = torch.stack([pre.mean(1), 1 / pre.std(1)], 1).contiguous()
+        gamma, beta = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
 
     def run(v):
+        if epi == 4:
+            rc = libs[v[0]].clip_gemm_bf16_lnres(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(pre), _lib.ptr(stats),
+                                                 _lib.ptr(gamma), _lib.ptr(beta), None, _lib.ptr(out), M, N, K, K, K, N, N,
+                                                 int(v[1]), _lib.stream_ptr())
+            assert rc == 0, rc
+            return
         rc = libs[v[0]].clip_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K,
                                        K, K, N, N if res is not None else 0, epi, int(f32), int(v[1]),
                                        _lib.stream_ptr())
