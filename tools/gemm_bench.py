@@ -33,6 +33,10 @@ for name, _ in variants:
 # epi 4 = the engine's residual form (fp32 LayerNorm output recomputed in the epilogue)
 shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 4, True), ("ffn_up", 3072, 768, 1, False),
           ("ffn_down", 768, 3072, 4, True)]
+if os.environ.get("SHAPES") == "res":   # what does the residual read cost the fp32-output GEMMs?
+    shapes = [("attn_out nores", 768, 768, 0, True), ("attn_out bf16res", 768, 768, 2, True), ("attn_out lnres", 768, 768, 4, True),
+              ("ffn_down nores", 768, 3072, 0, True), ("ffn_down bf16res", 768, 3072, 2, True), ("ffn_down lnres", 768, 3072, 4, True),
+              ("attn_out bf16out nores", 768, 768, 0, False)]
 g = torch.Generator(device="cpu").manual_seed(0)
 for sname, N, K, epi, f32 in shapes:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
