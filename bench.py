@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows-per-step", type=int, default=256)
+    ap.add_argument("--rows-per-step", type=int, default=255)
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
@@ -196,7 +196,7 @@ def main():
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bert_oracle as O    # CPU baseline leg only
-            sample = all_rows[:256]
+            sample = all_rows[:args.rows_per_step]
             t1 = time.perf_counter()
             _, keep_ref, score_ref, logits_ref = O.score_rows(sd, cfg, sample, n_ctx, batch_size=8)
             dt = time.perf_counter() - t1

@@ -69,6 +69,15 @@ struct clip_engine {
   // its epilogue re-derives the residual from pre[b] / stats[b] (EPI_BIAS_LNRES)
   float *pre[2] = {nullptr, nullptr}, *stats[2] = {nullptr, nullptr};
   float *pre_rows[2] = {nullptr, nullptr}, *stats_rows[2] = {nullptr, nullptr};
+  // fused-LayerNorm data flow (EPI_BIAS_LNOUT; bf16 setting, hidden a multiple of 256): the N = hidden
+  // GEMMs write the LayerNorm output themselves — x (bf16 operand) and xres (fp16 residual copy) —
+  // the column-tile workgroups of a row panel exchanging per-row sums through lnpart / lnflags
+  bool fuse_ln = true;
+  uint16_t* xres = nullptr;
+  float* lnpart = nullptr;
+  uint32_t* lnflags = nullptr;
+  int32_t* dev_err = nullptr;
+  uint32_t epoch = 0;
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -133,7 +142,15 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, &e->ctx_rows, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->mid_rows, S * I * es);
   for (int b = 0; b < 2; ++b) rc = rc ? rc : dev_alloc(e, (void**)&e->stats_rows[b], S * 8);
+  const size_t n_tiles = (Tp / 256) * ((H + 255) / 256);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->xres, Tp * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   if (rc) return rc;
+  HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
+  HIP_TRY(hipMemset(e->lnflags, 0, n_tiles * 4));
+  HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
   // persistent GEMM: keep them finite from the start
   HIP_TRY(hipMemset(e->x, 0, Tp * H * es));
@@ -368,8 +385,17 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
   // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
   // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
+  const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
   int cur = 0;
   const float *g_prev = e->embg, *b_prev = e->embb;
+  // fused flow: out = x (bf16) and xres (fp16, in place: a tile reads exactly the elements it rewrites)
+  auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
+                     const float* beta) {
+    GemmArgs a{A, W, bias, e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
+    a.ln_gamma = gamma; a.ln_beta = beta;
+    a.lnout = LnOutArgs{e->xres, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err};
+    return launch_gemm(a, st);
+  };
   auto res_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* pre_in,
                       const float* stats_in, float* pre_out, const int32_t* index) {
     GemmArgs a{A, W, bias, f32 ? e->x : (const void*)pre_in, pre_out, M, H, K, K, K, H, H,
@@ -381,8 +407,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
     HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
-                            c.type_vocab_size, st, f32, f32 ? nullptr : e->pre[0],
-                            f32 ? nullptr : e->stats[0]));
+                            c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
+                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres : nullptr));
   }
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
@@ -406,15 +432,20 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
         HIP_TRY(launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
                                  n_seqs, max_seqlen, c.num_heads, H, st));
     }
-    {
+    if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      HIP_TRY(res_gemm(e->ctx, L.wo, L.bo, Tg, H, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
-    }
-    cur ^= 1;
-    {
-      ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->pre[cur], L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32,
-                               f32 ? nullptr : e->stats[cur]));
+      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b));
+    } else {
+      {
+        ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
+        HIP_TRY(res_gemm(e->ctx, L.wo, L.bo, Tg, H, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
+      }
+      cur ^= 1;
+      {
+        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(e->pre[cur], L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32,
+                                 f32 ? nullptr : e->stats[cur]));
+      }
     }
     g_prev = L.ln1g; b_prev = L.ln1b;
     {
@@ -422,15 +453,20 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
       g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
-    {
+    if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      HIP_TRY(res_gemm(e->mid, L.wo2, L.bo2, Tg, I, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
-    }
-    cur ^= 1;
-    {
-      ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-      HIP_TRY(launch_layernorm(e->pre[cur], L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32,
-                               f32 ? nullptr : e->stats[cur]));
+      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b));
+    } else {
+      {
+        ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
+        HIP_TRY(res_gemm(e->mid, L.wo2, L.bo2, Tg, I, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
+      }
+      cur ^= 1;
+      {
+        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+        HIP_TRY(launch_layernorm(e->pre[cur], L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32,
+                                 f32 ? nullptr : e->stats[cur]));
+      }
     }
     g_prev = L.ln2g; b_prev = L.ln2b;
   }
@@ -445,7 +481,13 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
-      HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
+      if (fused) {
+        GemmArgs a{e->ctx_rows, L.wo, L.bo, e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H, EPI_BIAS_RES16, true};
+        a.res_index = focus;
+        HIP_TRY(launch_gemm(a, st));
+      } else {
+        HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
+      }
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
@@ -488,6 +530,22 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
                               c.num_labels, st, f32));
   }
+  return CLIP_OK;
+}
+
+int clip_set_fused_layernorm(clip_engine* e, int32_t on) {
+  if (!e) return fail(CLIP_ERR_ARG, "clip_set_fused_layernorm: null engine");
+  e->fuse_ln = on != 0;
+  return CLIP_OK;
+}
+
+int clip_poll_errors(clip_engine* e, int32_t* host_flags) {
+  if (!e || !host_flags) return fail(CLIP_ERR_ARG, "clip_poll_errors: null argument");
+  *host_flags = 0;
+  if (!e->dev_err) return CLIP_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(host_flags, e->dev_err, 4, hipMemcpyDeviceToHost));  // synchronises with the engine's work
+  if (*host_flags) HIP_TRY(hipMemset(e->dev_err, 0, 4));
   return CLIP_OK;
 }
 
@@ -553,6 +611,21 @@ int clip_gemm_bf16_lnres(const uint16_t* A, const uint16_t* W, const float* bias
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   if (res_index && (tile == 1 || tile == 2)) return fail(CLIP_ERR_ARG, "gemm: res_index needs a one-tile kernel");
   if (tile == 1) return fail(CLIP_ERR_ARG, "gemm: the LayerNorm-residual epilogue is not built for tile 1");
+  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_gemm_bf16_lnout(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res16,
+                         const float* gamma, const float* beta, float eps, uint16_t* x_out,
+                         uint16_t* xres_out, float* part, uint32_t* flags, uint32_t epoch, int32_t* err,
+                         int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
+                         int32_t ldres, void* stream) {
+  GemmArgs g{A, W, bias, res16, x_out, M, N, K, lda, ldw, ldo, ldres, EPI_BIAS_LNOUT, false, 2};
+  g.ln_gamma = gamma; g.ln_beta = beta;
+  g.lnout = LnOutArgs{xres_out, part, flags, epoch, eps, err};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  if (!res16 || !xres_out || !part || !flags || !err || N / 256 > 8)
+    return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout: null buffer, or more than 8 column tiles");
   HIP_TRY(launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }

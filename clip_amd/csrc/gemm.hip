@@ -244,6 +244,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
             v.x += ln_apply(rv.x, sv.x, sv.y, gv.x, be.x); v.y += ln_apply(rv.y, sv.x, sv.y, gv.y, be.y);
             v.z += ln_apply(rv.z, sv.x, sv.y, gv.z, be.z); v.w += ln_apply(rv.w, sv.x, sv.y, gv.w, be.w);
           }
+          if (EPI == EPI_BIAS_RES16) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+            const int rr = res_index ? res_index[m] : m;
+            const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + (size_t)rr * ldres + n);
+            v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+          }
           if (EPI == EPI_BIAS_RES) {
             if constexpr (F32IN) {
               const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + (size_t)m * ldres + n);
@@ -301,7 +307,10 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.epi == EPI_BIAS_RES && (!g.res || g.ldres % 4)) return "gemm: residual missing/misaligned";
   if (g.epi == EPI_BIAS_LNRES && (!g.res || g.ldres % 4 || !g.ln_stats || !g.ln_gamma || !g.ln_beta || !g.out_f32 || g.f32_in))
     return "gemm: LayerNorm-residual epilogue needs fp32 pre-LN rows, statistics, gamma, beta and an fp32 output";
-  if (g.res_index && g.epi != EPI_BIAS_LNRES) return "gemm: res_index only with the LayerNorm-residual epilogue";
+  if (g.epi == EPI_BIAS_RES16 && (!g.res || g.ldres % 4 || !g.out_f32 || g.f32_in)) return "gemm: fp16-residual epilogue needs fp16 rows and an fp32 output";
+  if (g.epi == EPI_BIAS_LNOUT && (g.tile != 2 || g.out_f32 || g.f32_in || !gemm_persist_ok(g) || !g.ln_gamma || !g.ln_beta))
+    return "gemm: the fused-LayerNorm epilogue runs on the ping-pong kernel only (tile 2, bf16 out, M and N multiples of 256)";
+  if (g.res_index && g.epi != EPI_BIAS_LNRES && g.epi != EPI_BIAS_RES16) return "gemm: res_index only with the residual-row epilogues";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
   if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1 && g.tile != 2) return "gemm: tile must be 0 (auto), 1 / 2 (persistent), 128 or 256";
   if ((g.tile == 1 || g.tile == 2) && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
@@ -321,7 +330,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   }
   if (g.res_index && (g.tile == 1 || g.tile == 2)) return hipErrorInvalidValue;
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
-                      !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index))
+                      !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index && g.epi != EPI_BIAS_RES16))
     return launch_gemm8(g, st);
   if (g.tile == 1) return launch_gemm_persist(g, st);
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
@@ -333,6 +342,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_TANH * 2 + 0: return launch_one<EPI_BIAS_TANH, false>(g, st);
     case EPI_BIAS_TANH * 2 + 1: return launch_one<EPI_BIAS_TANH, true>(g, st);
     case EPI_BIAS_LNRES * 2 + 1: return launch_one<EPI_BIAS_LNRES, true>(g, st);
+    case EPI_BIAS_RES16 * 2 + 1: return launch_one<EPI_BIAS_RES16, true>(g, st);
     default: return hipErrorInvalidValue;
   }
 }

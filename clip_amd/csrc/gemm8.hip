@@ -13,8 +13,8 @@
 //    so A0 and the B halves are dead after phase A, A1 after phase B: each slot is restaged at least
 //    one phase after its last read, and every phase's ds_reads are retired (lgkmcnt(0)) BEFORE the
 //    barrier that ends its load section -> no LDS-DMA can overwrite bytes still being read.
-//    (GEMM8_PH == 4 builds the finer schedule this grew from: 4 phases of 16 MFMAs, 7 half-tiles
-//    ahead, one counted vmcnt(6) per K tile; 4..9 % slower in the main loop.)
+//    (A finer schedule, 4 phases of 16 MFMAs with one counted vmcnt(6) per K tile, was 4..9 % slower
+//    in the main loop: git history.)
 //  * Each phase is  [load section: ds_reads + 4 LDS-DMA pieces + waits] barrier [32 MFMAs] barrier.
 //    Waves 4..7 run one barrier behind waves 0..3 (one extra barrier at tile start, balanced by one
 //    for waves 0..3 before the epilogue), and the two waves of a SIMD are one of each group: while
@@ -37,13 +37,11 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HT = 16384;            // half-tile: 128 rows x 128 B
 constexpr int RING = 8 * HT;         // 2 K tiles
 constexpr int SCR = 2048;            // epilogue scratch per wave
-constexpr int LDS8 = RING + 8 * SCR + 2 * 3072;  // + {bias, ln gamma, ln beta}[2][256] f32
+constexpr int LDS8 = RING + 8 * SCR + 2 * 3072 + 4096;  // + {bias, ln gamma, ln beta}[2][256] f32 + LNOUT row sums / stats
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 #ifndef GEMM8_ABLATE
 #define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue
-#endif
-#ifndef GEMM8_PH
-#define GEMM8_PH 2      // phases per K tile: 2 (32 MFMAs between barriers; main loop +4..9 %) or 4 (16)
 #endif
 #ifndef GEMM8_STORE
 #define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
@@ -59,7 +57,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int K, int lda, int ldw, int ldo,
     int ldres, int tiles_m, int tiles_n, int group_n, const float2* __restrict__ ln_stats,
-    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta) {
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, LnOutArgs lo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16_t* res = reinterpret_cast<const bf16_t*>(resv);
 
@@ -76,6 +74,16 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   const int panels = tiles_m >> 3;
   const int items = panels * tiles_n;
   auto tile_at = [&](int i, int& tm_o, int& tn_o) -> bool {
+    if (EPI == EPI_BIAS_LNOUT) {
+      // groups of tiles_n neighbouring workgroups (same XCD but for a few) take one row panel at a
+      // time, member k always computing column tile k: they run side by side (and re-synchronise at
+      // every statistics exchange), share the A panel through L2 and keep their W tile
+      const int lin = xcd * per_x + slot;
+      const int n_groups = G / tiles_n, grp = lin / tiles_n;
+      tn_o = lin - grp * tiles_n;
+      tm_o = grp + n_groups * i;
+      return grp < n_groups && tm_o < tiles_m;
+    }
     if (group_n > 0) {
       const int q = slot + per_x * i;
       if (q >= items) return false;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slices: uniform counts
     char* dst = reinterpret_cast<char*>(bias_lds) + buf * 3072;
     __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + lane * 4), LDS_PTR(dst), 16, 0, 0);
-    if (EPI == EPI_BIAS_LNRES) {
+    if (EPI == EPI_BIAS_LNRES || EPI == EPI_BIAS_LNOUT) {
       __builtin_amdgcn_global_load_lds(GLB_PTR(ln_gamma + tn_x * BN + lane * 4), LDS_PTR(dst + 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GLB_PTR(ln_beta + tn_x * BN + lane * 4), LDS_PTR(dst + 2048), 16, 0, 0);
     }
@@ -146,12 +154,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     advance();  // c1 = K tile 1, c2 = K tile 2 (or the next tile's first)
     stage_half(a1, a_off, lda, 4);
     stage_half(w1, w_off, ldw, 5);
-#if GEMM8_PH == 2
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#else
-    stage_half(w1 + (size_t)128 * ldw, w_off, ldw, 6);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#endif
     __builtin_amdgcn_s_barrier();
   }
 
@@ -182,7 +185,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
     for (int kk = 0; kk < nt; kk += 2) {
-#if GEMM8_PH == 2
       auto ktile = [&]<int B>() {
         const char* buf = smem + B * 4 * HT;
         // ---------------- phase A: A0, both B n-halves -> acc[0][*]; stage (t+1).B1, (t+1).A1
@@ -259,101 +261,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         __builtin_amdgcn_s_barrier();
         advance();
       };
-#else
-      auto ktile = [&]<int B>() {
-        const char* buf = smem + B * 4 * HT;
-        // ---------------- P1: A0, B n-half 0 -> acc[0][0]; stage (t+1).A1
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bf0[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c0);
-          bf0[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c1);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c0);
-          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c1);
-        }
-        if (B == 1 && kk == 0 && has_next) stage_bias(ntn, (it + 1) & 1);
-        if (v1) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              acc[0][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[0][0][m][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P2: B n-half 1 -> acc[0][1]; stage (t+2).A0
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bf1[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c0);
-          bf1[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
-        }
-        if (v2) stage_half(a2, a_off, lda, B * 4 + 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              acc[0][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[0][1][m][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P3: A1 -> acc[1][1]; stage (t+2).B0
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
-          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
-        }
-        if (v2) stage_half(w2, w_off, ldw, B * 4 + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              acc[1][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[1][1][m][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---------------- P4: -> acc[1][0]; stage (t+2).B1; K tile t+1 retired one barrier early
-        if (v2) {
-          stage_half(w2 + (size_t)128 * ldw, w_off, ldw, B * 4 + 2);
-          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              acc[1][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[1][0][m][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        advance();
-      };
-#endif
       ktile.template operator()<0>();
       ktile.template operator()<1>();
     }
@@ -376,6 +283,138 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(acc[mh][nh][m][i]));
+    } else if (EPI == EPI_BIAS_LNOUT) {
+      // ---- fused LayerNorm.  (1) v = acc + bias + fp16 residual, in accumulator layout
+      const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#ifdef LNOUT_NORES   // diagnostic builds
+              const f16x4_t r = {0, 0, 0, 0}; (void)res16; (void)rg;
+#else
+              const f16x4_t r = res16[(rg + n_base + nh * 32 + i * 16 + fq * 4) >> 2];
+#endif
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[e];
+            }
+        }
+      // (2) per-row (sum, sum of squares) over this wave's 64 columns -> LDS, one slot per column wave
+      float2* part_lds = reinterpret_cast<float2*>(smem + RING);                       // [4][256], in the scratch
+      float2* tot_lds = reinterpret_cast<float2*>(smem + RING + 8 * SCR + 2 * 3072);   // [256] this tile's sums
+      float2* stat_lds = tot_lds + 256;                                                // [256] (mean, rstd)
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float sm = 0.f, sq = 0.f;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = acc[mh][nh][m][i][e];
+                sm += v;
+                sq = fmaf(v, v, sq);
+              }
+          sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+          sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+          if (fq == 0) part_lds[wc * 256 + mh * 128 + wr * 64 + m * 16 + fr] = make_float2(sm, sq);
+        }
+      __syncthreads();
+      // (3) the workgroup's 256-column partial per row: published write-through (sc1 stores, every
+      // storing wave drained, barrier), then the flag (MI355X_MICROARCH.md, inter-workgroup hand-off)
+      const int tile_id = tm * tiles_n + tn;
+      if (tid < 256) {
+        const float2 p0 = part_lds[tid], p1 = part_lds[256 + tid], p2 = part_lds[512 + tid], p3 = part_lds[768 + tid];
+        const float2 P = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+        tot_lds[tid] = P;
+        unsigned long long bits;
+        __builtin_memcpy(&bits, &P, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(lo.part) + (size_t)tile_id * 256 + tid, bits,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(lo.flags + tile_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (4) wait for the other column tiles of this row panel (lane 0 of wave k polls tile k), bounded:
+      // the partners are resident and one tile-time away at most, unless the GPU is shared
+#ifndef LNOUT_NOSYNC  // diagnostic builds
+      if (lane == 0 && w < tiles_n && w != tn) {
+        const uint32_t* f = lo.flags + tm * tiles_n + w;
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lo.epoch) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 23)) { atomicOr(lo.err, 2); break; }
+        }
+      }
+#endif
+      __syncthreads();
+      if (tid < 256) {
+        float2 T = make_float2(0.f, 0.f);
+        for (int k = 0; k < tiles_n; ++k) {  // fixed order: every tile of the panel gets the same bits
+          float2 P;
+          if (k == tn) {
+            P = tot_lds[tid];
+          } else {
+            const unsigned long long bits = __hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(lo.part) + (size_t)(tm * tiles_n + k) * 256 + tid,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_memcpy(&P, &bits, 8);
+          }
+          T.x += P.x; T.y += P.y;
+        }
+        const float inv_n = 1.0f / (float)(tiles_n * BN);
+        const float mean = T.x * inv_n;
+        const float var = fmaxf(fmaf(T.y, inv_n, -mean * mean), 0.f);
+        stat_lds[tid] = make_float2(mean, 1.0f / sqrtf(var + lo.eps));
+      }
+      __syncthreads();
+      // (5) normalise in registers, then two transposed passes per 16-row block: bf16 x and fp16 residual
+      const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + fq * 4;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float2 st = stat_lds[mh * 128 + wr * 64 + m * 16 + fr];
+          const size_t m0 = (size_t)tm * BM + mh * 128 + wr * 64 + m * 16;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(gl + nh * 32 + i * 16);
+                const f32x4_t be = *reinterpret_cast<const f32x4_t*>(gl + 256 + nh * 32 + i * 16);
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = ln_apply(acc[mh][nh][m][i][e], st.x, st.y, gv[e], be[e]);
+                const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
+                uint2 pk;
+                if (pass == 0) {
+                  pk = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                } else {
+                  const f16x4_t hv = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+                  __builtin_memcpy(&pk, &hv, 8);
+                }
+                *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) = pk;
+              }
+            uint16_t* dst = pass == 0 ? reinterpret_cast<uint16_t*>(out) : lo.xres_out;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+              const uint4 v = *reinterpret_cast<const uint4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
+              out_store(*reinterpret_cast<const u32x4_t*>(&v),
+                        reinterpret_cast<u32x4_t*>(dst + (m0 + row) * ldo + n_base + c16 * 8));
+            }
+          }
+        }
     } else if (!OUT_F32) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
@@ -499,7 +538,7 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS8, st, static_cast<const bf16_t*>(g.A),
                      static_cast<const bf16_t*>(g.W), g.bias, g.res, g.out, g.K,
                      g.lda, g.ldw, g.ldo, g.ldres, tiles_m, tiles_n, group_n,
-                     reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta);
+                     reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta, g.lnout);
   return hipGetLastError();
 }
 
@@ -515,6 +554,10 @@ hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_RES * 2 + 0: return launch_8<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
     case EPI_BIAS_LNRES * 2 + 1: return launch_8<EPI_BIAS_LNRES, true>(g, st);
+    case EPI_BIAS_LNOUT * 2 + 0:
+      if (g.N / BN > 8 || !g.lnout.xres_out || !g.lnout.part || !g.lnout.flags || !g.lnout.err || !g.res)
+        return hipErrorInvalidValue;
+      return launch_8<EPI_BIAS_LNOUT, false>(g, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -5,7 +5,25 @@
 // EPI_BIAS_LNRES: out_f32 = A W^T + bias + LayerNorm(pre)[m, n], the residual operand recomputed in
 // fp32 from the producer's pre-LayerNorm row (`res` = pre, fp32), its row statistics and affine —
 // what the reference adds is the fp32 LayerNorm output (modeling_bert.py:292,350), not a bf16 copy.
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3, EPI_BIAS_LNRES = 4 };
+// EPI_BIAS_LNOUT (ping-pong kernel only, N = the whole row): the LayerNorm itself is fused,
+//   v = A W^T + bias + res16[m, n];  x_bf16, xres_f16 = LayerNorm(v) over the N columns of row m.
+// The N / 256 workgroups that compute the column tiles of one 256-row panel run side by side (a
+// fixed group of neighbouring workgroups, each keeping its column tile across panels, so the A
+// panel is fetched once into their XCD's L2) and exchange per-row (sum, sum of squares) through
+// device memory before normalising their accumulators.  No pre-LayerNorm tensor reaches HBM and
+// there is no LayerNorm kernel.
+// EPI_BIAS_RES16: out_f32 = A W^T + bias + fp16 residual rows (optionally picked by res_index).
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3, EPI_BIAS_LNRES = 4,
+       EPI_BIAS_LNOUT = 5, EPI_BIAS_RES16 = 6 };
+
+struct LnOutArgs {         // EPI_BIAS_LNOUT
+  uint16_t* xres_out;      // [M, N] fp16 LayerNorm output (the next residual; may alias res); out = bf16 copy
+  float* part;             // [tiles_m * tiles_n * 256] (sum, sumsq) pairs, scratch
+  uint32_t* flags;         // [tiles_m * tiles_n] last epoch published
+  uint32_t epoch;          // differs from every earlier launch on these flags
+  float eps;
+  int32_t* err;            // |= 2 when a partner tile's statistics did not arrive (bounded spin)
+};
 
 struct GemmArgs {
   const void* A;      // [M, K] activations (bf16; fp32 when f32_in), row stride lda (elements)
@@ -23,6 +41,7 @@ struct GemmArgs {
   const float* ln_gamma = nullptr;   // [N]
   const float* ln_beta = nullptr;    // [N]
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
+  LnOutArgs lnout = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
@@ -50,11 +69,13 @@ hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const in
                            const float* word, const float* pos, const float* type,
                            const float* gamma, const float* beta, float eps, void* out, int T,
                            int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
-                           bool out_f32 = false, float* pre_out = nullptr, float* stats = nullptr);
+                           bool out_f32 = false, float* pre_out = nullptr, float* stats = nullptr,
+                           uint16_t* res16 = nullptr);  // res16: optional fp16 copy of the output
 // out_bf16[t] = LayerNorm(x_f32[t])
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
                             void* out, int T, int H, hipStream_t st, bool out_f32 = false,
-                            float* stats = nullptr);  // stats: optional [T] (mean, rstd) pairs out
+                            float* stats = nullptr,      // optional [T] (mean, rstd) pairs out
+                            uint16_t* res16 = nullptr);  // optional fp16 copy of the output
 // dst[i] = src[rows[i]]  (bf16 rows of H)
 hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
                               hipStream_t st, bool f32 = false);

@@ -26,7 +26,7 @@ __device__ __forceinline__ void load_vec(const float* p, float* dst) {
 template <int VEC, int NIT, bool OUT_F32>
 __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gamma,
                                           const float* beta, float eps, void* outv, int H,
-                                          int lane, float2* stats_row) {
+                                          int lane, float2* stats_row, uint16_t* res16 = nullptr) {
   bf16_t* out = reinterpret_cast<bf16_t*>(outv);
   float* outf = reinterpret_cast<float*>(outv);
   float s = 0.f;
@@ -54,6 +54,13 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
     float y[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) y[v] = ln_apply(x[it][v], mean, rstd, g[v], b[v]);
+    if (res16) {  // fp16 copy of the same fp32 values: the residual operand of EPI_BIAS_LNOUT / RES16
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const _Float16 hv = (_Float16)y[v];
+        res16[e + v] = *reinterpret_cast<const uint16_t*>(&hv);
+      }
+    }
     if (OUT_F32) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) outf[e + v] = y[v];
@@ -70,7 +77,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         void* __restrict__ out, int T, int H,
-                                                        float2* __restrict__ stats) {
+                                                        float2* __restrict__ stats,
+                                                        uint16_t* __restrict__ res16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
   ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
                                reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane,
-                               stats ? stats + row : nullptr);
+                               stats ? stats + row : nullptr, res16 ? res16 + (size_t)row * H : nullptr);
 }
 
 // BertEmbeddings.forward (transformers modeling_bert.py:68-108): word + token_type + position
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
     const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     void* __restrict__ out, int T, int H, int vocab, int max_pos, int type_vocab,
-    float* __restrict__ pre_out, float2* __restrict__ stats) {
+    float* __restrict__ pre_out, float2* __restrict__ stats, uint16_t* __restrict__ res16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(
   }
   ln_finish<VEC, NIT, OUT_F32>(x, gamma, beta, eps,
                                reinterpret_cast<char*>(out) + (size_t)row * H * (OUT_F32 ? 4 : 2), H, lane,
-                               stats ? stats + row : nullptr);
+                               stats ? stats + row : nullptr, res16 ? res16 + (size_t)row * H : nullptr);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src,
@@ -307,11 +315,12 @@ hipError_t ln_dispatch(int H, bool f32, F&& f) {
 }  // namespace
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            void* out, int T, int H, hipStream_t st, bool out_f32, float* stats) {
+                            void* out, int T, int H, hipStream_t st, bool out_f32, float* stats,
+                            uint16_t* res16) {
   if (T <= 0) return hipSuccess;
   return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
     hipLaunchKernelGGL((layernorm_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, x,
-                       gamma, beta, eps, out, T, H, reinterpret_cast<float2*>(stats));
+                       gamma, beta, eps, out, T, H, reinterpret_cast<float2*>(stats), res16);
     return hipGetLastError();
   });
 }
@@ -320,12 +329,12 @@ hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const in
                            const float* word, const float* pos, const float* type,
                            const float* gamma, const float* beta, float eps, void* out, int T,
                            int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
-                           bool out_f32, float* pre_out, float* stats) {
+                           bool out_f32, float* pre_out, float* stats, uint16_t* res16) {
   if (T <= 0) return hipSuccess;
   return ln_dispatch(H, out_f32, [&]<int VEC, int NIT, bool F32>() {
     hipLaunchKernelGGL((embed_ln_kernel<VEC, NIT, F32>), dim3((T + 3) / 4), dim3(256), 0, st, ids,
                        type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H, vocab,
-                       max_pos, type_vocab, pre_out, reinterpret_cast<float2*>(stats));
+                       max_pos, type_vocab, pre_out, reinterpret_cast<float2*>(stats), res16);
     return hipGetLastError();
   });
 }

@@ -133,6 +133,19 @@ int clip_gemm_bf16_lnres(const uint16_t* dev_A, const uint16_t* dev_W, const flo
                          const int32_t* dev_res_index, float* dev_out, int32_t M, int32_t N,
                          int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres,
                          int32_t tile, void* stream);
+/* The fused form (ping-pong kernel; M, N multiples of 256, N <= 2048, K a multiple of 128):
+ *   v = A W^T + bias + res16[m, :] (fp16);  x_out (bf16), xres_out (fp16) = LayerNorm_{gamma,beta,eps}(v)
+ * over the N columns of each row (BertSelfOutput / BertOutput, modeling_bert.py:289-293, 347-351, in
+ * one kernel, no pre-LayerNorm tensor in HBM).  The N/256 workgroups computing the column tiles of a
+ * 256-row panel run side by side and exchange per-row sums through dev_part ((M/256)*(N/256)*256
+ * float pairs) and dev_flags ((M/256)*(N/256) uint32, zero before first use); `epoch` must differ from
+ * every earlier call on the same flags; dev_err |= 2 if a partner never published (clip_poll_errors).
+ * xres_out may alias res16 (each workgroup rewrites exactly the elements it read). */
+int clip_gemm_bf16_lnout(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                         const uint16_t* dev_res16, const float* dev_gamma, const float* dev_beta,
+                         float eps, uint16_t* dev_x_out, uint16_t* dev_xres_out, float* dev_part,
+                         uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M, int32_t N,
+                         int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, void* stream);
 /* fp32 check mode of the same GEMM kernel: fp32 operands, residual and output, exact-fp32 MFMA
  * (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  K a multiple of 32. */
 int clip_gemm_f32(const float* dev_A, const float* dev_W, const float* dev_bias,
@@ -161,6 +174,18 @@ int clip_embed_layernorm(const int32_t* dev_ids, const int32_t* dev_type_ids,
  * that row only (M = n_seqs instead of total_tokens); off = every token through every layer, as
  * transformers BertModel does.  Same result up to rounding (tests compare both). */
 int clip_set_trim_last_layer(clip_engine* e, int32_t on);
+
+/* The bf16 setting fuses each LayerNorm into the GEMM that feeds it when hidden_size is a multiple of
+ * 256 (default on): the column-tile workgroups of a 256-row panel exchange per-row sums through
+ * device memory and write the LayerNorm output themselves, as the bf16 GEMM operand and as an fp16
+ * residual copy (clip_gemm_bf16_lnout).  Off = GEMM -> fp32 pre-LayerNorm rows -> LayerNorm kernel,
+ * the residual recomputed in fp32; same result to within bf16 rounding (tests compare both).  The
+ * choice never depends on the batch, so a row's logits do not either. */
+int clip_set_fused_layernorm(clip_engine* e, int32_t on);
+/* Device-side error word of the engine since the last poll (synchronises with its stream work):
+ * bit 1 = a fused-LayerNorm tile's partner statistics did not arrive within the spin bound (a GPU
+ * shared with work that kept a workgroup from being scheduled); results of that call are void. */
+int clip_poll_errors(clip_engine* e, int32_t* host_flags);
 
 /* HIP-event timing of the kernels inside clip_forward_packed, for bench.py's roofline figure (no
  * counterpart in the reference, which has no profiling: SURVEY.md 5).  Bit k of kind_mask turns

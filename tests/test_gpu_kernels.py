@@ -371,3 +371,40 @@ def test_gemm_layernorm_residual_epilogue(lib, M, N, K, tile, indexed):
     if tile == 2:
         assert torch.equal(out, run(256))
         assert torch.equal(out, run(2))
+
+
+@pytest.mark.parametrize("M,N,K", [(255 * 256, 768, 768), (64 * 256, 768, 768), (36 * 256, 768, 3072), (256, 768, 768),
+                                   (5 * 256, 256, 256), (3 * 256, 1024, 512), (100 * 256, 512, 256)])
+def test_gemm_fused_layernorm_epilogue(lib, M, N, K):
+    """x, xres = LayerNorm(A W^T + bias + res16): the LayerNorm runs inside the GEMM, its row sums
+    exchanged between the N/256 column-tile workgroups of each row panel.  Against an fp64
+    reference; twice (the second call re-uses flags and scratch under a new epoch, and must give
+    the same bits); in place (xres receives the output)."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = (torch.randn(M, N, generator=g) * 1.5 + 0.2).to(torch.float16).cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    nt = (M // 256) * (N // 256)
+    part = torch.empty(nt * 256 * 2, device="cuda")
+    flags = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    v = A.double() @ W.double().T + bias.double() + res.double()
+    ref, _, _ = _ln_ref(v, gamma.double(), beta.double())
+    outs = []
+    for epoch in (1, 2):
+        x = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        xres = res.clone()      # in place: the residual buffer receives the fp16 output
+        _lib.check(lib.clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(xres), _lib.ptr(gamma),
+                                            _lib.ptr(beta), 1e-12, _lib.ptr(x), _lib.ptr(xres), _lib.ptr(part),
+                                            _lib.ptr(flags), epoch, _lib.ptr(err), M, N, K, K, K, N, N,
+                                            _lib.stream_ptr()))
+        _sync()
+        assert int(err.item()) == 0
+        assert torch.isfinite(x.float()).all() and torch.isfinite(xres.float()).all()
+        assert (xres.double() - ref).abs().max().item() < 4e-3 + 2 ** -10 * ref.abs().max().item()
+        assert (x.double() - ref).abs().max().item() < 4e-3 + 2 ** -8 * ref.abs().max().item()
+        outs.append((x.clone(), xres.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -152,3 +152,27 @@ def test_precision_is_fixed_at_finalize(golden):
     assert _lib.load().clip_set_precision(h, _lib.PRECISION_FP32) == _lib.CLIP_ERR_STATE
     with pytest.raises(ValueError):
         model.set_precision("fp16")
+
+
+@pytest.mark.parametrize("name", ["base_ctx", "base_sent"])
+def test_fused_layernorm_equals_unfused(golden, name):
+    """EPI_BIAS_LNOUT (LayerNorm fused into the N = hidden GEMMs) against the GEMM -> LayerNorm-kernel
+    flow: same logits to within bf16 rounding, both inside the budget against the reference."""
+    import ctypes as C
+    from clip_amd import _lib
+    g = golden(name)
+    model = build_model(g)
+    h = model._ensure_engine()
+    fused, _ = run_padded(model, g)
+    flags = C.c_int32(-1)
+    _lib.check(_lib.load().clip_poll_errors(h, C.byref(flags)))
+    assert flags.value == 0     # no statistics exchange timed out
+    _lib.check(_lib.load().clip_set_fused_layernorm(h, 0))
+    unfused, _ = run_padded(model, g)
+    assert np.abs(fused - g["ref_logits"]).max() < BF16_LOGIT_TOL
+    assert np.abs(unfused - g["ref_logits"]).max() < BF16_LOGIT_TOL
+    assert np.abs(fused - unfused).max() < 1e-2
+    # deterministic: the exchange order is fixed, so a second run gives the same bits
+    _lib.check(_lib.load().clip_set_fused_layernorm(h, 1))
+    again, _ = run_padded(model, g)
+    assert np.array_equal(fused, again)

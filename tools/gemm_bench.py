@@ -29,10 +29,15 @@ for name, _ in variants:
         lib.clip_gemm_bf16.restype = C.c_int
         lib.clip_gemm_bf16_lnres.argtypes = _lib.SIGNATURES["clip_gemm_bf16_lnres"]
         lib.clip_gemm_bf16_lnres.restype = C.c_int
+        lib.clip_gemm_bf16_lnout.argtypes = _lib.SIGNATURES["clip_gemm_bf16_lnout"]
+        lib.clip_gemm_bf16_lnout.restype = C.c_int
         libs[name] = lib
 # epi 4 = the engine's residual form (fp32 LayerNorm output recomputed in the epilogue)
 shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 4, True), ("ffn_up", 3072, 768, 1, False),
           ("ffn_down", 768, 3072, 4, True)]
+if os.environ.get("SHAPES") == "ln":    # fused LayerNorm (epi 5) against GEMM + residual recompute (epi 4; + a 46 us LayerNorm kernel)
+    shapes = [("attn_out lnres", 768, 768, 4, True), ("attn_out lnout", 768, 768, 5, False),
+              ("ffn_down lnres", 768, 3072, 4, True), ("ffn_down lnout", 768, 3072, 5, False)]
 if os.environ.get("SHAPES") == "res":   # what does the residual read cost the fp32-output GEMMs?
     shapes = [("attn_out nores", 768, 768, 0, True), ("attn_out bf16res", 768, 768, 2, True), ("attn_out lnres", 768, 768, 4, True),
               ("ffn_down nores", 768, 3072, 0, True), ("ffn_down bf16res", 768, 3072, 2, True), ("ffn_down lnres", 768, 3072, 4, True),
@@ -49,7 +54,24 @@ for sname, N, K, epi, f32 in shapes:
         stats = torch.stack([pre.mean(1), 1 / pre.std(1)], 1).contiguous()
         gamma, beta = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
 
+    if epi == 5:
+        res16 = torch.randn(M, N, generator=g).to(torch.float16).cuda()
+        xres = torch.empty_like(res16)
+        part = torch.empty((M // 256) * (N // 256) * 512, device="cuda")
+        flags = torch.zeros((M // 256) * (N // 256), dtype=torch.int32, device="cuda")
+        errw = torch.zeros(1, dtype=torch.int32, device="cuda")
+        gamma, beta = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+        epoch = [0]
+
     def run(v):
+        if epi == 5:
+            epoch[0] += 1
+            rc = libs[v[0]].clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res16), _lib.ptr(gamma),
+                                                 _lib.ptr(beta), 1e-12, _lib.ptr(out), _lib.ptr(xres), _lib.ptr(part),
+                                                 _lib.ptr(flags), epoch[0], _lib.ptr(errw), M, N, K, K, K, N, N,
+                                                 _lib.stream_ptr())
+            assert rc == 0, rc
+            return
         if epi == 4:
             rc = libs[v[0]].clip_gemm_bf16_lnres(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(pre), _lib.ptr(stats),
                                                  _lib.ptr(gamma), _lib.ptr(beta), None, _lib.ptr(out), M, N, K, K, K, N, N,
