@@ -42,7 +42,7 @@ SIGNATURES = {
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
     "clip_gemm_bf16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_bf16_lnres": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
-    "clip_gemm_bf16_lnout": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, C.c_uint32, _p,
+    "clip_gemm_bf16_lnout": [_p, _p, _p, _p, _i32, _p, _p, _f, _p, _p, _p, _p, C.c_uint32, _p,
                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
@@ -52,6 +52,7 @@ SIGNATURES = {
     "clip_set_trim_last_layer": [_p, _i32],
     "clip_set_fused_layernorm": [_p, _i32],
     "clip_poll_errors": [_p, _p],
+    "clip_preferred_step_tokens": [_p, _p],
     "clip_profile_enable": [_p, C.c_uint32],
     "clip_profile_read": [_p, _p, _p, _i32],
     "clip_last_error": [],

@@ -44,6 +44,24 @@ __device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float
   return fmaf((x - mean) * rstd, g, b);
 }
 
+// The fp16 residual copy of the fused-LayerNorm flow is kept TILED for the accumulator layout of the
+// 256x256 GEMM tile, so that the workgroup that wrote a tile reads it back (as the next residual)
+// with whole 1-KiB wave accesses and no transpose.  Element (row, col) of an [M, N] tensor, N a
+// multiple of 256, M padded to 256, tiles_n = N / 256:
+//   tile = (row >> 8) * tiles_n + (col >> 8);  r = row & 255, c = col & 255
+//   wave = ((r >> 6) & 1) * 4 + (c >> 6)          (wr, wc)
+//   blk  = (r >> 7) * 4 + ((r >> 4) & 3)          (mh, m: the 16-row block)
+//   lane = ((c >> 2) & 3) * 16 + (r & 15)         (fq, fr)
+//   nh = (c >> 5) & 1, i = (c >> 4) & 1, e = c & 3
+//   offset = ((tile * 8 + wave) * 8 + blk) * 1024 + nh * 512 + lane * 8 + i * 4 + e
+__host__ __device__ __forceinline__ size_t xres_tiled_offset(int row, int col, int tiles_n) {
+  const int r = row & 255, c = col & 255;
+  const size_t tile = (size_t)(row >> 8) * tiles_n + (col >> 8);
+  const int wave = ((r >> 6) & 1) * 4 + (c >> 6), blk = (r >> 7) * 4 + ((r >> 4) & 3);
+  const int lane = ((c >> 2) & 3) * 16 + (r & 15);
+  return ((tile * 8 + wave) * 8 + blk) * 1024 + ((c >> 5) & 1) * 512 + lane * 8 + ((c >> 4) & 1) * 4 + (c & 3);
+}
+
 // erf-GELU as torch's nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // below fp32 resolution of the surrounding sum and ~5x cheaper than libm erff in a GEMM epilogue).
 __device__ __forceinline__ float erf_as(float x) {

@@ -73,7 +73,8 @@ struct clip_engine {
   // GEMMs write the LayerNorm output themselves — x (bf16 operand) and xres (fp16 residual copy) —
   // the column-tile workgroups of a row panel exchanging per-row sums through lnpart / lnflags
   bool fuse_ln = true;
-  uint16_t* xres = nullptr;
+  uint16_t *xres = nullptr;     // tiled (xres_tiled_offset): written and re-read in place by the fused GEMMs
+  uint16_t *xres_rm = nullptr;  // row-major: the embedding LayerNorm's copy, residual of the first fused GEMM
   float* lnpart = nullptr;
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
@@ -144,11 +145,13 @@ int alloc_workspace(clip_engine* e) {
   for (int b = 0; b < 2; ++b) rc = rc ? rc : dev_alloc(e, (void**)&e->stats_rows[b], S * 8);
   const size_t n_tiles = (Tp / 256) * ((H + 255) / 256);
   rc = rc ? rc : dev_alloc(e, (void**)&e->xres, Tp * H * 2);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   if (rc) return rc;
   HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
+  HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
   HIP_TRY(hipMemset(e->lnflags, 0, n_tiles * 4));
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
@@ -388,12 +391,15 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
   int cur = 0;
   const float *g_prev = e->embg, *b_prev = e->embb;
-  // fused flow: out = x (bf16) and xres (fp16, in place: a tile reads exactly the elements it rewrites)
+  // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
+  // rewrites); the very first residual is the embedding LayerNorm's row-major copy
+  bool first_res = true;
   auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
                      const float* beta) {
-    GemmArgs a{A, W, bias, e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
+    GemmArgs a{A, W, bias, first_res ? e->xres_rm : e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta;
-    a.lnout = LnOutArgs{e->xres, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err};
+    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err};
+    first_res = false;
     return launch_gemm(a, st);
   };
   auto res_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* pre_in,
@@ -408,7 +414,7 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
                             c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
-                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres : nullptr));
+                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres_rm : nullptr));
   }
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
@@ -482,8 +488,11 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
       if (fused) {
-        GemmArgs a{e->ctx_rows, L.wo, L.bo, e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H, EPI_BIAS_RES16, true};
+        // (a one-layer model trims its only layer: the residual is still the embedding's row-major copy)
+        GemmArgs a{e->ctx_rows, L.wo, L.bo, first_res ? e->xres_rm : e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H,
+                   EPI_BIAS_RES16, true};
         a.res_index = focus;
+        a.res_tiles_n = first_res ? 0 : H / 256;
         HIP_TRY(launch_gemm(a, st));
       } else {
         HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
@@ -536,6 +545,21 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
 int clip_set_fused_layernorm(clip_engine* e, int32_t on) {
   if (!e) return fail(CLIP_ERR_ARG, "clip_set_fused_layernorm: null engine");
   e->fuse_ln = on != 0;
+  return CLIP_OK;
+}
+
+int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens) {
+  if (!e || !tokens) return fail(CLIP_ERR_ARG, "clip_preferred_step_tokens: null argument");
+  const clip_config& c = e->cfg;
+  *tokens = c.max_tokens;
+  const int H = c.hidden_size;
+  if (e->f32 || !e->fuse_ln || H % 256 || H / 256 > 8 || c.intermediate_size % 128) return CLIP_OK;
+  int cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+  // the fused-LayerNorm GEMMs run (CUs / column tiles) row panels of 256 tokens side by side: whole
+  // rounds of that many panels leave no CU idle (MI355X, hidden 768: 85 panels = 21 760 tokens)
+  const int round_tokens = ((cus & ~7) / (H / 256)) * 256;
+  if (round_tokens > 0 && c.max_tokens >= round_tokens) *tokens = c.max_tokens / round_tokens * round_tokens;
   return CLIP_OK;
 }
 
@@ -616,13 +640,13 @@ int clip_gemm_bf16_lnres(const uint16_t* A, const uint16_t* W, const float* bias
 }
 
 int clip_gemm_bf16_lnout(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res16,
-                         const float* gamma, const float* beta, float eps, uint16_t* x_out,
+                         int32_t res_tiled, const float* gamma, const float* beta, float eps, uint16_t* x_out,
                          uint16_t* xres_out, float* part, uint32_t* flags, uint32_t epoch, int32_t* err,
                          int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldo,
                          int32_t ldres, void* stream) {
   GemmArgs g{A, W, bias, res16, x_out, M, N, K, lda, ldw, ldo, ldres, EPI_BIAS_LNOUT, false, 2};
   g.ln_gamma = gamma; g.ln_beta = beta;
-  g.lnout = LnOutArgs{xres_out, part, flags, epoch, eps, err};
+  g.lnout = LnOutArgs{xres_out, res_tiled != 0, part, flags, epoch, eps, err};
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   if (!res16 || !xres_out || !part || !flags || !err || N / 256 > 8)
     return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout: null buffer, or more than 8 column tiles");

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
     int ldo, int ldres, int tiles_m, int tiles_n, const float2* __restrict__ ln_stats,
     const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
-    const int32_t* __restrict__ res_index) {
+    const int32_t* __restrict__ res_index, int res_tiles_n) {
   static_assert(!F32IN || OUT_F32, "fp32 operands imply fp32 output");
   constexpr int ESZ = F32IN ? 4 : 2;       // operand element bytes
   constexpr int BKE = 128 / ESZ;           // K elements per tile (128-byte LDS rows)
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
           if (EPI == EPI_BIAS_RES16) {
             typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
             const int rr = res_index ? res_index[m] : m;
-            const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + (size_t)rr * ldres + n);
+            const size_t ro = res_tiles_n > 0 ? xres_tiled_offset(rr, n, res_tiles_n) : (size_t)rr * ldres + n;
+            const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + ro);
             v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
           }
           if (EPI == EPI_BIAS_RES) {
@@ -283,7 +284,7 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n), dim3(64 * WAVES_M * WAVES_N), LDS, st, g.A, g.W,
                      g.bias, g.res, g.out, g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldres, tiles_m,
                      tiles_n, reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta,
-                     g.res_index);
+                     g.res_index, g.res_tiles_n);
   return hipGetLastError();
 }
 

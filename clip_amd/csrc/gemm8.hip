@@ -52,7 +52,7 @@ __device__ __forceinline__ void out_store(V v, V* p) {
   else *p = v;
 }
 
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool RES_TILED = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int K, int lda, int ldw, int ldo,
@@ -284,26 +284,45 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 #pragma unroll
             for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(acc[mh][nh][m][i]));
     } else if (EPI == EPI_BIAS_LNOUT) {
-      // ---- fused LayerNorm.  (1) v = acc + bias + fp16 residual, in accumulator layout
-      const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
+      // ---- fused LayerNorm.  (1) v = acc + bias + fp16 residual, in accumulator layout.  The residual
+      // is the tiled copy an earlier launch of this epilogue wrote (1-KiB wave loads), or, for the first
+      // layer, the row-major copy of the embedding LayerNorm.
+      typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+      const size_t xt_base = (((size_t)tm * tiles_n + tn) * 8 + w) * 8192 + lane * 8;  // + blk * 1024 + nh * 512
+      if (RES_TILED) {
+        const uint16_t* rt = reinterpret_cast<const uint16_t*>(resv) + xt_base;
 #pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < 2; ++mh) {
+          __builtin_amdgcn_sched_barrier(0);  // 8 loads (32 registers) in flight at a time, not 16
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
+          for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int nh = 0; nh < 2; ++nh)
+            for (int nh = 0; nh < 2; ++nh) {
+              const f16x8_t r = *reinterpret_cast<const f16x8_t*>(rt + (mh * 4 + m) * 1024 + nh * 512);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#ifdef LNOUT_NORES   // diagnostic builds
-              const f16x4_t r = {0, 0, 0, 0}; (void)res16; (void)rg;
-#else
-              const f16x4_t r = res16[(rg + n_base + nh * 32 + i * 16 + fq * 4) >> 2];
-#endif
+              for (int i = 0; i < 2; ++i)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[e];
+                for (int e = 0; e < 4; ++e)
+                  acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[i * 4 + e];
             }
         }
+      } else {
+        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const f16x4_t r = res16[(rg + n_base + nh * 32 + i * 16 + fq * 4) >> 2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[e];
+              }
+          }
+      }
       // (2) per-row (sum, sum of squares) over this wave's 64 columns -> LDS, one slot per column wave
       float2* part_lds = reinterpret_cast<float2*>(smem + RING);                       // [4][256], in the scratch
       float2* tot_lds = reinterpret_cast<float2*>(smem + RING + 8 * SCR + 2 * 3072);   // [256] this tile's sums
@@ -376,8 +395,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         stat_lds[tid] = make_float2(mean, 1.0f / sqrtf(var + lo.eps));
       }
       __syncthreads();
-      // (5) normalise in registers, then two transposed passes per 16-row block: bf16 x and fp16 residual
+      // (5) normalise in registers; the fp16 residual copy goes out tiled straight from the registers
+      // (1-KiB wave stores), the bf16 GEMM operand through the transpose scratch as whole row segments
       const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + fq * 4;
+      uint16_t* xt = lo.xres_out + xt_base;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -385,34 +406,31 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           const float2 st = stat_lds[mh * 128 + wr * 64 + m * 16 + fr];
           const size_t m0 = (size_t)tm * BM + mh * 128 + wr * 64 + m * 16;
 #pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
+          for (int nh = 0; nh < 2; ++nh) {
+            f16x8_t hv;
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
+            for (int i = 0; i < 2; ++i) {
+              const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(gl + nh * 32 + i * 16);
+              const f32x4_t be = *reinterpret_cast<const f32x4_t*>(gl + 256 + nh * 32 + i * 16);
+              float y[4];
 #pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(gl + nh * 32 + i * 16);
-                const f32x4_t be = *reinterpret_cast<const f32x4_t*>(gl + 256 + nh * 32 + i * 16);
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = ln_apply(acc[mh][nh][m][i][e], st.x, st.y, gv[e], be[e]);
-                const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
-                uint2 pk;
-                if (pass == 0) {
-                  pk = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
-                } else {
-                  const f16x4_t hv = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
-                  __builtin_memcpy(&pk, &hv, 8);
-                }
-                *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) = pk;
+              for (int e = 0; e < 4; ++e) {
+                y[e] = ln_apply(acc[mh][nh][m][i][e], st.x, st.y, gv[e], be[e]);
+                hv[i * 4 + e] = (_Float16)y[e];
               }
-            uint16_t* dst = pass == 0 ? reinterpret_cast<uint16_t*>(out) : lo.xres_out;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              const int row = p * 8 + (lane >> 3), c16 = lane & 7;
-              const uint4 v = *reinterpret_cast<const uint4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
-              out_store(*reinterpret_cast<const u32x4_t*>(&v),
-                        reinterpret_cast<u32x4_t*>(dst + (m0 + row) * ldo + n_base + c16 * 8));
+              const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
+              *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
+                  make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
             }
+            out_store(*reinterpret_cast<const u32x4_t*>(&hv),
+                      reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
+          }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
+            out_store(*reinterpret_cast<const u32x4_t*>(&v),
+                      reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(out) + (m0 + row) * ldo + n_base + c16 * 8));
           }
         }
     } else if (!OUT_F32) {
@@ -511,9 +529,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool RES_TILED = false>
 hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
-  auto kfn = gemm8_kernel<EPI, OUT_F32>;
+  auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED>;
   static int n_cu = 0;
   if (n_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -557,7 +575,7 @@ hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_LNOUT * 2 + 0:
       if (g.N / BN > 8 || !g.lnout.xres_out || !g.lnout.part || !g.lnout.flags || !g.lnout.err || !g.res)
         return hipErrorInvalidValue;
-      return launch_8<EPI_BIAS_LNOUT, false>(g, st);
+      return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true>(g, st) : launch_8<EPI_BIAS_LNOUT, false, false>(g, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -17,7 +17,8 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES = 2, EPI_BIAS_TANH = 3, EPI
        EPI_BIAS_LNOUT = 5, EPI_BIAS_RES16 = 6 };
 
 struct LnOutArgs {         // EPI_BIAS_LNOUT
-  uint16_t* xres_out;      // [M, N] fp16 LayerNorm output (the next residual; may alias res); out = bf16 copy
+  uint16_t* xres_out;      // [M, N] fp16 LayerNorm output, TILED (xres_tiled_offset); may alias a tiled res
+  bool res_tiled;          // res is tiled like xres_out (false: row-major fp16 with row stride ldres)
   float* part;             // [tiles_m * tiles_n * 256] (sum, sumsq) pairs, scratch
   uint32_t* flags;         // [tiles_m * tiles_n] last epoch published
   uint32_t epoch;          // differs from every earlier launch on these flags
@@ -41,7 +42,8 @@ struct GemmArgs {
   const float* ln_gamma = nullptr;   // [N]
   const float* ln_beta = nullptr;    // [N]
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
-  LnOutArgs lnout = {nullptr, nullptr, nullptr, 0, 0.f, nullptr};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
+  int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles
+  LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);

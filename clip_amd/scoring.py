@@ -12,6 +12,7 @@ not depend on which rows share its step (tests/test_gpu_model.py::test_packed_pa
 so bucketing changes nothing but speed.
 """
 import csv
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
@@ -83,6 +84,10 @@ class BulkScorer:
         self.any_threshold = float(any_threshold)
         self.label_threshs = None if label_threshs is None else np.asarray(label_threshs, np.float64)
         self.keep_probs = keep_probs
+        if tokens_per_step is None and model.device.type == "cuda":
+            t = C.c_int32(0)     # whole rounds of the fused-LayerNorm GEMMs (clip_preferred_step_tokens)
+            _lib.check(_lib.load().clip_preferred_step_tokens(model._ensure_engine(), C.byref(t)))
+            tokens_per_step = t.value
         self.tokens_per_step = int(tokens_per_step or model.max_tokens)
         self.max_rows_per_step = int(max_rows_per_step or model.max_seqs)
         if self.tokens_per_step > model.max_tokens or self.max_rows_per_step > model.max_seqs:
@@ -136,6 +141,11 @@ class BulkScorer:
                     _lib.ptr(logits), _lib.ptr(thr), self.any_threshold, n, L,
                     _lib.ptr(out_p[a:b]) if out_p is not None else None, _lib.ptr(out_max[a:b]),
                     _lib.ptr(out_lab[a:b]) if out_lab is not None else None, _lib.ptr(out_keep[a:b]), stream))
+            dev_flags = C.c_int32(0)
+            _lib.check(lib.clip_poll_errors(engine, C.byref(dev_flags)))
+            if dev_flags.value:
+                raise RuntimeError(f"engine error word {dev_flags.value}: a fused-LayerNorm exchange timed out "
+                                   "(GPU shared with other work?); results discarded")
             if int(err.item()) != 0:
                 raise TypeError(f"a row does not hold exactly {2 * self.n_ctx + 1} [SEP] tokens "
                                 "(sentclf/bert_model.py:51-55)")

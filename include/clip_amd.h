@@ -140,9 +140,15 @@ int clip_gemm_bf16_lnres(const uint16_t* dev_A, const uint16_t* dev_W, const flo
  * 256-row panel run side by side and exchange per-row sums through dev_part ((M/256)*(N/256)*256
  * float pairs) and dev_flags ((M/256)*(N/256) uint32, zero before first use); `epoch` must differ from
  * every earlier call on the same flags; dev_err |= 2 if a partner never published (clip_poll_errors).
- * xres_out may alias res16 (each workgroup rewrites exactly the elements it read). */
+ * xres_out is TILED for the kernel's accumulator layout: element (row, col) at
+ *   ((tile*8 + wave)*8 + blk)*1024 + nh*512 + lane*8 + i*4 + e,  tile = (row>>8)*(N/256) + (col>>8),
+ *   r = row&255, c = col&255, wave = ((r>>6)&1)*4 + (c>>6), blk = (r>>7)*4 + ((r>>4)&3),
+ *   lane = ((c>>2)&3)*16 + (r&15), nh = (c>>5)&1, i = (c>>4)&1, e = c&3
+ * (whole 1-KiB wave stores, and whole 1-KiB loads when the next call takes it as its residual).
+ * res_tiled != 0: dev_res16 is such a tiled tensor and may be xres_out itself (a workgroup rewrites
+ * exactly the elements it read); 0: row-major fp16 with row stride ldres, not aliasing xres_out. */
 int clip_gemm_bf16_lnout(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
-                         const uint16_t* dev_res16, const float* dev_gamma, const float* dev_beta,
+                         const uint16_t* dev_res16, int32_t res_tiled, const float* dev_gamma, const float* dev_beta,
                          float eps, uint16_t* dev_x_out, uint16_t* dev_xres_out, float* dev_part,
                          uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M, int32_t N,
                          int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, void* stream);
@@ -182,6 +188,9 @@ int clip_set_trim_last_layer(clip_engine* e, int32_t on);
  * the residual recomputed in fp32; same result to within bf16 rounding (tests compare both).  The
  * choice never depends on the batch, so a row's logits do not either. */
 int clip_set_fused_layernorm(clip_engine* e, int32_t on);
+/* Packed tokens per forward call that fill the GPU in whole rounds of the fused-LayerNorm GEMMs
+ * (<= max_tokens; = max_tokens when that flow is not in use).  The bulk driver sizes its steps by it. */
+int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens);
 /* Device-side error word of the engine since the last poll (synchronises with its stream work):
  * bit 1 = a fused-LayerNorm tile's partner statistics did not arrive within the spin bound (a GPU
  * shared with work that kept a workgroup from being scheduled); results of that call are void. */

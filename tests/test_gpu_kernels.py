@@ -373,13 +373,25 @@ def test_gemm_layernorm_residual_epilogue(lib, M, N, K, tile, indexed):
         assert torch.equal(out, run(2))
 
 
+def _xres_tiled_offsets(M, N):
+    """include/clip_amd.h, clip_gemm_bf16_lnout: where element (row, col) of the tiled fp16 copy lives"""
+    row = torch.arange(M).view(-1, 1)
+    col = torch.arange(N).view(1, -1)
+    r, c = row & 255, col & 255
+    tile = (row >> 8) * (N // 256) + (col >> 8)
+    wave = ((r >> 6) & 1) * 4 + (c >> 6)
+    blk = (r >> 7) * 4 + ((r >> 4) & 3)
+    lane = ((c >> 2) & 3) * 16 + (r & 15)
+    return ((tile * 8 + wave) * 8 + blk) * 1024 + ((c >> 5) & 1) * 512 + lane * 8 + ((c >> 4) & 1) * 4 + (c & 3)
+
+
 @pytest.mark.parametrize("M,N,K", [(255 * 256, 768, 768), (64 * 256, 768, 768), (36 * 256, 768, 3072), (256, 768, 768),
                                    (5 * 256, 256, 256), (3 * 256, 1024, 512), (100 * 256, 512, 256)])
 def test_gemm_fused_layernorm_epilogue(lib, M, N, K):
     """x, xres = LayerNorm(A W^T + bias + res16): the LayerNorm runs inside the GEMM, its row sums
     exchanged between the N/256 column-tile workgroups of each row panel.  Against an fp64
-    reference; twice (the second call re-uses flags and scratch under a new epoch, and must give
-    the same bits); in place (xres receives the output)."""
+    reference; with the residual row-major (first layer) and tiled + in place (every later layer),
+    which must give the same bits, also across calls (new epoch on the same flags / scratch)."""
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
@@ -391,20 +403,31 @@ def test_gemm_fused_layernorm_epilogue(lib, M, N, K):
     part = torch.empty(nt * 256 * 2, device="cuda")
     flags = torch.zeros(nt, dtype=torch.int32, device="cuda")
     err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    off = _xres_tiled_offsets(M, N).cuda()
+    assert torch.equal(off.flatten().sort().values, torch.arange(M * N, device="cuda"))   # a permutation
+    res_tiled = torch.empty(M * N, dtype=torch.float16, device="cuda")
+    res_tiled[off.flatten()] = res.flatten()
     v = A.double() @ W.double().T + bias.double() + res.double()
     ref, _, _ = _ln_ref(v, gamma.double(), beta.double())
     outs = []
-    for epoch in (1, 2):
+    for epoch, tiled in ((1, False), (2, False), (3, True)):
         x = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        xres = res.clone()      # in place: the residual buffer receives the fp16 output
-        _lib.check(lib.clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(xres), _lib.ptr(gamma),
-                                            _lib.ptr(beta), 1e-12, _lib.ptr(x), _lib.ptr(xres), _lib.ptr(part),
-                                            _lib.ptr(flags), epoch, _lib.ptr(err), M, N, K, K, K, N, N,
+        if tiled:
+            xres = res_tiled.clone()   # in place: the tiled residual buffer receives the tiled output
+            rin = xres
+        else:
+            xres = torch.full((M * N,), float("nan"), dtype=torch.float16, device="cuda")
+            rin = res
+        _lib.check(lib.clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(rin), int(tiled),
+                                            _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(x), _lib.ptr(xres),
+                                            _lib.ptr(part), _lib.ptr(flags), epoch, _lib.ptr(err), M, N, K, K, K, N, N,
                                             _lib.stream_ptr()))
         _sync()
         assert int(err.item()) == 0
-        assert torch.isfinite(x.float()).all() and torch.isfinite(xres.float()).all()
-        assert (xres.double() - ref).abs().max().item() < 4e-3 + 2 ** -10 * ref.abs().max().item()
+        xr = xres[off]                 # back to [M, N]
+        assert torch.isfinite(x.float()).all() and torch.isfinite(xr.float()).all()
+        assert (xr.double() - ref).abs().max().item() < 4e-3 + 2 ** -10 * ref.abs().max().item()
         assert (x.double() - ref).abs().max().item() < 4e-3 + 2 ** -8 * ref.abs().max().item()
         outs.append((x.clone(), xres.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
