@@ -71,7 +71,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   const int G = gridDim.x, per_x = G >> 3;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int n_tiles = tiles_m * tiles_n;
-  const int panels = tiles_m >> 3;
+  // row panels are dealt to the 8 XCDs in contiguous runs (the first tiles_m % 8 XCDs take one more)
+  const int panels = (tiles_m >> 3) + (xcd < (tiles_m & 7) ? 1 : 0);
+  const int panel0 = xcd * (tiles_m >> 3) + min(xcd, tiles_m & 7);
   const int items = panels * tiles_n;
   auto tile_at = [&](int i, int& tm_o, int& tn_o) -> bool {
     if (EPI == EPI_BIAS_LNOUT) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       const int per_group = panels * group_n;
       const int g = q / per_group, r = q - g * per_group;
       const int m = r / group_n;
-      tm_o = xcd * panels + m;
+      tm_o = panel0 + m;
       tn_o = g * group_n + (r - m * group_n);
       return true;
     }
@@ -547,7 +549,7 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
   const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
   // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream
   int group_n = 0;
-  if (tiles_m % 8 == 0) {
+  if (tiles_m >= 8) {
     group_n = tiles_n;
     if ((long)tiles_n * BN * g.K * 2 > 1700000 && g.K < 2048)
       for (int d = 1; d <= tiles_n; ++d)
