@@ -1,0 +1,166 @@
+"""Full-size synthetic scoring jobs (BASELINE.json configs C2 / C4 / C5) end to end on one node:
+
+    python -m clip_amd.job --config C4 --rows 10000000 --topk 250000
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m clip_amd.job --config C5 --rows 50000000 --topk 250000 --out ttp_top250000.csv
+
+The loop of /root/reference/sentclf/apply_bert_unlabeled.py:92-124 at NOTEEVENTS scale: rows arrive
+in CHUNKS of whole documents (here generated, MIMIC being access-controlled; a real run streams the
+columnar file of clip_amd.collate.build_rows), chunk c belongs to rank c % world (documents are the
+sharding unit), a rank scores its chunks with no communication and keeps only a
+RUNNING top-k (k records, 16 B each: memory does not grow with the corpus), and the job ends with
+the one all-gather + deterministic merge of clip_amd.topk.  Chunk contents depend on (seed, chunk
+index) only, so the global top-k is the same for every world size — the property
+tests/test_gpu_job.py checks.
+"""
+import argparse
+import csv
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import synth, topk
+from .scoring import BulkScorer, PackedRows
+
+CONFIGS = {   # name -> (n_ctx, max_len, sigma, seg_hi, seed)      SURVEY.md §8d
+    "C2": (0, 64, 0.6, 62, 1001),
+    "C3": (2, 256, 0.6, 62, 1002),
+    "C4": (2, 256, 0.6, 62, 1004),
+    "C5": (2, 512, 0.9, 200, 1005),
+}
+DOC_STRIDE = 1 << 24      # doc ids of chunk c start at c * DOC_STRIDE: unique without coordination
+
+
+def chunk_rows(config, chunk_index, n_rows, vocab_size):
+    """Rows of one chunk: (PackedRows, doc_ids int64, sent_ixs int64); documents of 40..400 sentences."""
+    n_ctx, max_len, sigma, seg_hi, seed = CONFIGS[config]
+    flat, off = synth.packed_context_rows(n_rows, n_ctx, vocab_size, max_len, seed=seed * 1000003 + chunk_index,
+                                          sigma=sigma, seg_hi=seg_hi)
+    d, s = synth.documents(n_rows, seed=seed * 7919 + chunk_index)
+    return PackedRows(flat, off), d + chunk_index * DOC_STRIDE, s.astype(np.int64)
+
+
+class RunningTopK:
+    """Best k records seen so far under the total order of clip_amd.topk (bounded memory)."""
+
+    def __init__(self, k):
+        self.k = int(k)
+        self.records = np.empty(0, topk.RECORD)
+
+    def update(self, doc_ids, sent_ixs, scores, keep=None):
+        new = topk.local_topk(doc_ids, sent_ixs, scores, self.k, keep=keep)
+        self.records = topk.merge_topk([self.records, new], self.k)
+        return self
+
+
+def run_rank(scorer, config, n_rows, chunk_rows_n, k, rank, world, vocab_size, on_chunk=None):
+    """Score this rank's chunks; returns (RunningTopK, rows, tokens, kept)."""
+    n_chunks = (n_rows + chunk_rows_n - 1) // chunk_rows_n
+    top = RunningTopK(k)
+    rows_done = tokens = kept = 0
+    for c in range(rank, n_chunks, world):
+        n = min(chunk_rows_n, n_rows - c * chunk_rows_n)
+        rows, doc_ids, sent_ixs = chunk_rows(config, c, n, vocab_size)
+        res = scorer.score(rows, doc_ids, sent_ixs)
+        top.update(res.doc_ids, res.sent_ixs, res.max_score, keep=res.keep)
+        rows_done += n
+        tokens += int(rows.lens.sum())
+        kept += int(res.keep.sum())
+        if on_chunk is not None:
+            on_chunk(c, n, res)
+    return top, rows_done, tokens, kept
+
+
+def write_topk_csv(path, records):
+    """The focus file of task-targeted pre-training: header doc_id,sent_ix as
+    sentclf/pretrain_tasks.py:37,57-58 reads it, score last."""
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["doc_id", "sent_ix", "max_label_score"])
+        for r in records:
+            w.writerow([r["doc_id"], r["sent_ix"], r["score"]])
+
+
+def main(argv=None):
+    from .bert_model import args_to_model
+    from .config import BertConfig
+    from .weights import procedural_state_dict
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C4")
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--chunk-rows", type=int, default=250_000)
+    ap.add_argument("--topk", type=int, default=250_000)
+    ap.add_argument("--threshold", type=float, default=0.05)
+    ap.add_argument("--tokens-per-step", type=int, default=65536)
+    ap.add_argument("--weights", type=str, default=None, help="state dict (.safetensors); default: procedural")
+    ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = BertConfig()
+    n_ctx = CONFIGS[args.config][0]
+    model = args_to_model(n_ctx)(cfg, max_tokens=args.tokens_per_step, max_seqs=max(64, args.tokens_per_step // 4))
+    if args.weights:
+        from safetensors.torch import load_file
+        model.load_state_dict(load_file(args.weights))
+    else:
+        model.load_state_dict(procedural_state_dict(cfg, 0))
+    model.to(device).eval()
+    if n_ctx > 0:
+        model.set_sep_token_id(102)
+        model.set_n_context_sentences(n_ctx)
+    model.set_task("multilabel")
+    scorer = BulkScorer(model, any_threshold=args.threshold)
+    warm, _, _ = chunk_rows(args.config, 0, 2048, cfg.vocab_size)
+    scorer.score(warm)                                    # engine build + first launches, untimed
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    top, rows_done, tokens, kept = run_rank(scorer, args.config, args.rows, args.chunk_rows, args.topk, rank, world,
+                                            cfg.vocab_size)
+    torch.cuda.synchronize()
+    t_score = time.perf_counter() - t0
+    glob = topk.global_topk(top.records, args.topk)
+    barrier()
+    t_all = time.perf_counter() - t0
+    tot = torch.tensor([rows_done, tokens, kept], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(tot)
+    if rank == 0:
+        if args.out:
+            write_topk_csv(args.out, glob)
+        print(json.dumps({
+            "job": args.config, "rows": int(tot[0]), "tokens": int(tot[1]), "kept": int(tot[2]), "n_gpus": world,
+            "seconds": round(t_all, 3), "rank0_scoring_seconds": round(t_score, 3),
+            "sentences_per_s": round(int(tot[0]) / t_all, 1), "tokens_per_s": round(int(tot[1]) / t_all, 1),
+            "topk": int(len(glob)), "topk_first": [int(glob[0]["doc_id"]), int(glob[0]["sent_ix"]), float(glob[0]["score"])]
+            if len(glob) else None,
+            "topk_last_score": float(glob[-1]["score"]) if len(glob) else None,
+            "data": "synthetic (clip_amd.synth.packed_context_rows), procedural weights, host generation + "
+                    "bucketing + H2D + D2H inside the timed region"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return glob
+
+
+if __name__ == "__main__":
+    main()

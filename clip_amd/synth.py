@@ -78,3 +78,35 @@ def documents(n_rows, seed=1004, lo=40, hi=400):
         i += n
         d += 1
     return doc_ids, sent_ixs
+
+
+def packed_context_rows(n_rows, n_ctx=2, vocab_size=30522, max_len=256, seed=1004, sigma=0.6, seg_hi=62):
+    """Bulk form of context_rows for the full-size configs (C4: 10 M rows, C5: 50 M): the same row
+    layout and segment-length law, built with array operations only, returned columnar as
+    (flat int32 ids, int64 offsets) — the input of clip_amd.scoring.PackedRows.  Rows longer than
+    max_len lose OUTER context tokens first (outermost pair, then the next pair, then the focus);
+    a [SEP] is never dropped.  n_ctx = 0 gives sentence-only rows ([CLS] w.. [SEP])."""
+    rng = np.random.default_rng(seed)
+    nseg = 2 * n_ctx + 1
+    seg = _seg_lengths(rng, n_rows * nseg, sigma=sigma, hi=seg_hi).reshape(n_rows, nseg)
+    overhead = 1 + nseg
+    excess = np.maximum(seg.sum(1) + overhead - max_len, 0)
+    for d in range(n_ctx, 0, -1):               # outermost pair first
+        lo, hi = n_ctx - d, n_ctx + d
+        take_lo = np.minimum(seg[:, lo], (excess + 1) // 2)
+        take_hi = np.minimum(seg[:, hi], excess - take_lo)
+        take_lo = np.minimum(seg[:, lo], excess - take_hi)   # what the other side could not give
+        seg[:, lo] -= take_lo
+        seg[:, hi] -= take_hi
+        excess -= take_lo + take_hi
+    seg[:, n_ctx] -= excess
+    if int(seg[:, n_ctx].min()) < 1:
+        raise ValueError("max_len too small for the focus sentence")
+    lens = seg.sum(1) + overhead
+    offsets = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    flat = rng.integers(1000, vocab_size, int(offsets[-1]), dtype=np.int32)
+    flat[offsets[:-1]] = CLS_ID
+    # the [SEP] closing segment s of row r sits at offsets[r] + 1 + sum(seg[r, :s+1]) + s
+    sep_pos = offsets[:-1, None] + 1 + np.cumsum(seg, 1) + np.arange(nseg)[None, :]
+    flat[sep_pos.ravel()] = SEP_ID
+    return flat, offsets
