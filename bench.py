@@ -28,6 +28,7 @@ from clip_amd.config import BertConfig  # noqa: E402
 from clip_amd.weights import procedural_state_dict  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_FILE = "r01_v10_pmc_traffic.json"
 DNOTE_THRESHS = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
 
 
@@ -63,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows-per-step", type=int, default=255)
+    ap.add_argument("--rows-per-step", type=int, default=510)
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
@@ -164,11 +165,14 @@ def main():
         achieved = gemm_flops / (avg_ms * 1e-3) / 1e12
         model_flops = sum(flops_per_row(int(L), cfg) for L in batches[0]["lens"])
         # HBM bytes per launch of the dominant kernel: from separate rocprofv3 --pmc passes
-        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py), kept under profiles/; null if absent
+        # (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py), kept under profiles/; null if absent or
+        # collected at another step size
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v8_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["gemm8_kernel<1, false>"]["hbm_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
+                pmc = json.load(fh)
+            if pmc.get("rows_per_step") == args.rows_per_step and pmc.get("seq_len") == args.seq_len:
+                traffic = pmc["kernels"]["gemm8_kernel<1, false, false>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         res = {
@@ -187,7 +191,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/r01_v8_pmc_traffic.json); algorithmic operand+output bytes = %d" % (2 * T * H + 2 * I * H + 2 * T * I),
+                         "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/%s); algorithmic operand+output bytes = %d" % (PMC_FILE, 2 * T * H + 2 * I * H + 2 * T * I),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
         }

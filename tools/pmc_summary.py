@@ -2,10 +2,10 @@
 FETCH_SIZE on gfx950 reports half the bytes of wide (16 B/lane) coalesced reads
 (MI355X_MICROARCH.md §HBM; confirmed here on layernorm_kernel: 100.7 MB reported for 201.3 MB read),
 so fetch is doubled; WRITE_SIZE is exact for 16-B stores.  Usage:
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json"""
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json [rows_per_step seq_len]"""
 import collections, csv, json, re, sys
 
-PAT = re.compile(r"(gemm8_kernel<\d, \w+>|gemm_persist_kernel<\d, \w+>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
+PAT = re.compile(r"(gemm8_kernel<\d, \w+(?:, \w+)?>|gemm_persist_kernel<\d, \w+>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
                  r"layernorm_kernel|embed_ln_kernel)")
 
 
@@ -22,6 +22,7 @@ F, n = load("FETCH_SIZE", sys.argv[1])
 W, _ = load("WRITE_SIZE", sys.argv[2])
 out = {k: {"launches": n[k], "fetch_bytes_reported": F[k], "fetch_bytes_corrected_x2": 2 * F[k],
            "write_bytes": W.get(k, 0.0), "hbm_bytes_per_launch": 2 * F[k] + W.get(k, 0.0)} for k in F}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
+meta = {"rows_per_step": int(sys.argv[4]), "seq_len": int(sys.argv[5])} if len(sys.argv) > 5 else {}
+json.dump({**meta, "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
     print(f"{k:40s} fetch {v['fetch_bytes_corrected_x2']/1e6:8.1f} MB  write {v['write_bytes']/1e6:8.1f} MB")
