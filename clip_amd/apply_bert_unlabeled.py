@@ -26,12 +26,11 @@ import torch
 
 from . import topk as topk_mod
 from .bert_model import args_to_model
-from .collate import build_rows
+from .fast_tokenizer import FastWordPiece, build_rows_fast
 from .config import BertConfig
 from .constants import LABEL_TYPES
 from .datasets import SentDataset, SentEvalDataset
 from .scoring import BulkScorer, PackedRows, ScoreResult, write_ttp_csv
-from .wordpiece import BertWordPieceTokenizer
 
 
 def main(argv=None):
@@ -61,7 +60,8 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    tokenizer = BertWordPieceTokenizer(os.path.join(args.model, "vocab.txt"))          # :43-47
+    # C++ WordPiece on all host cores (libclip_tok.so); the Python restatement behind it takes what it flags
+    tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                   # :43-47
     config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
     model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,
                                                     max_seqs=max(64, args.tokens_per_step // 8))  # :64-70
@@ -82,7 +82,7 @@ def main(argv=None):
     else:
         dataset = SentEvalDataset(args.unlabeled_fname, args.task,
                                   n_context_sentences=args.n_context_sentences)
-    rows, doc_ids, sent_ixs = build_rows(dataset, tokenizer, args.n_context_sentences)
+    rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
     a, b = topk_mod.shard_documents(doc_ids, rows.lens, world, rank)
     shard = PackedRows(rows.flat[rows.offsets[a]:rows.offsets[b]], rows.offsets[a:b + 1] - rows.offsets[a])
     res = BulkScorer(model, any_threshold=args.threshold).score(shard, doc_ids[a:b], sent_ixs[a:b])

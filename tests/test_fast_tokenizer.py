@@ -1,0 +1,130 @@
+"""libclip_tok.so (C++ WordPiece front end, include/clip_tok.h) against the Python restatement
+clip_amd/wordpiece.py — itself pinned by goldens from HF's BertTokenizer under the reference's
+collators (tests/test_frontend.py).  Integer work: bit-exact."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from clip_amd import collate, datasets, fast_tokenizer as FT
+from clip_amd.wordpiece import BertWordPieceTokenizer
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOCAB = os.path.join(G, "vocab.txt")
+
+
+@pytest.fixture(scope="module")
+def fast():
+    return FT.FastWordPiece(VOCAB, n_threads=4)
+
+
+def test_library_exports_every_declared_symbol():
+    src = open(os.path.join(ROOT, "include", "clip_tok.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(clip_tok_[a-z0-9_]+)\s*\(", src)))
+    lib = FT.load()
+    assert names == sorted(FT.SIGNATURES) and len(names) == 6
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.clip_tok_create(None, 1, None) == -1 and b"null" in lib.clip_tok_last_error()
+    assert lib.clip_tok_create(b"/nonexistent/vocab.txt", 1, FT.C.byref(FT.C.c_void_p())) == -2
+
+
+def _rows_of(flat, off):
+    return [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+
+def test_text_mode_matches_python_tokenizer(fast):
+    vocab_words = [w for w in fast.vocab if w.isascii() and not w.startswith("[")]
+    rng = np.random.default_rng(0)
+    texts = ["", " ", "[SEP] [SEP]", "x" * 101, "x" * 100, "Pt should F/U w/ Dr. Smith in 2 wks.",
+             "tab\tnew\nline\rcr", "ctl\x00a\x01b\x7fc\x1fd\x0be\x0cf", "[CLS]foo[MASK]bar[PAD][UNK] [sep] [SEP]x",
+             "don't  stop -- (ever)!?", "[", "[SE", "a[SEP", "MiXeD CaSe TEXT", "naïve café", "日本語 text", "Σίσυφος",
+             "� replacement", "ab" * 300]
+    for _ in range(300):      # sentences from vocabulary words, glued and spaced at random
+        k = int(rng.integers(1, 30))
+        ws = rng.choice(vocab_words, k)
+        texts.append("".join(w.replace("##", "") + (" " if rng.random() < 0.8 else "") for w in ws))
+    for _ in range(300):      # every ASCII byte, uniformly
+        texts.append(bytes(rng.integers(0, 128, int(rng.integers(0, 80))).astype(np.uint8)).decode("ascii"))
+    flat, off, fb = fast.encode_plain_many(texts)
+    ref = [fast.py.encode_plain(t) for t in texts]
+    assert _rows_of(flat, off) == ref
+    assert [t for t, f in zip(texts, fb) if f] == [t for t in texts if not t.isascii()]   # only those fall back
+    # thread count changes nothing
+    one = FT.FastWordPiece(VOCAB, n_threads=1)
+    big = texts * 20
+    a = fast.encode_plain_many(big)
+    b = one.encode_plain_many(big)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_cased_tokenizer(tmp_path):
+    f = FT.FastWordPiece(VOCAB, do_lower_case=False, n_threads=2)
+    texts = ["Hello World", "the Patient", "[SEP] The end."]
+    flat, off, _ = f.encode_plain_many(texts)
+    assert _rows_of(flat, off) == [f.py.encode_plain(t) for t in texts]
+
+
+def test_list_cell_mode_matches_python_path(fast):
+    cells = pd.read_csv(os.path.join(G, "notes_synth.csv"))["sentence"].tolist()
+    n_csv = len(cells)
+    cells += ["[]", "['a']", "['a',]", "[ 'a' , \"b\" ]", "['it\\'s', \"say \\\"hi\\\"\", 'back\\\\slash']",
+              "['tab\\there', 'nl\\nthere']", "['Caps', 'AND', 'MORE']", "['[SEP]', 'x']",
+              # left to Python: not plain quoted strings / not a list literal / non-ASCII
+              "[1, 2]", "['a', 2.50]", "['a' 'b']", "[['a']]", "[u'a']", "['''a''']", "['\\x41']", "['\\u00e9']",
+              "plain words here", "('a', 'b')", " ['a']", "['a'", "['café']", "['a', None]", "['a'] + ['b']"]
+    from clip_amd.datasets import _parse_list
+    text = lambda i: " ".join(str(x) for x in _parse_list(cells[i], lower=False)).lower()
+    flat, off, fb = fast.encode_plain_many(cells, FT.MODE_LIST_CELL, py_text=text)
+    assert _rows_of(flat, off) == [fast.py.encode_plain(text(i)) for i in range(len(cells))]
+    handled = dict(zip(cells, ~fb))
+    assert handled["['it\\'s', \"say \\\"hi\\\"\", 'back\\\\slash']"] and handled["['a',]"] and handled["[]"]
+    assert not handled["[1, 2]"] and not handled["['\\x41']"] and not handled["plain words here"]
+    assert fb[n_csv:].sum() == 15
+    assert [c.isascii() for c in cells[:n_csv]] == list(~fb[:n_csv])       # CSV cells: only non-ASCII ones fall back
+
+
+def _synthetic_csv(path, n_docs=60, seed=3):
+    """Documents of 1..80 sentences of vocabulary words; some duplicated / skipped sentence indices
+    (the <DOC_END> mismatch branch), a few very long sentences (rows reaching 512 tokens)."""
+    rng = np.random.default_rng(seed)
+    tok = BertWordPieceTokenizer(VOCAB)
+    words = [w for w in tok.vocab if w.isascii() and w.isalpha() and len(w) > 1]
+    rows = []
+    for d in range(n_docs):
+        k = int(rng.integers(1, 80))
+        ixs = list(range(k))
+        if k > 5 and rng.random() < 0.3:
+            ixs[int(rng.integers(1, k))] = int(rng.integers(0, k))       # duplicate / out-of-order index
+        for s in ixs:
+            L = int(rng.integers(1, 40)) if rng.random() > 0.02 else int(rng.integers(150, 700))
+            sent = [str(w).capitalize() if rng.random() < 0.2 else str(w) for w in rng.choice(words, L)]
+            if rng.random() < 0.1:
+                sent.append("it's")
+            if rng.random() < 0.01:
+                sent.append("café")
+            rows.append({"doc_id": 1000 + d, "sent_index": s, "sentence": str(sent), "labels": "[]"})
+    pd.DataFrame(rows).to_csv(path, index=False)
+    return len(rows)
+
+
+@pytest.mark.parametrize("n", [2, 1, 0])
+def test_build_rows_fast_equals_build_rows(fast, tmp_path, n):
+    paths = [os.path.join(G, "notes_synth.csv"), os.path.join(G, "dummy_test_data.csv"), str(tmp_path / "big.csv")]
+    _synthetic_csv(paths[2])
+    for path in paths:
+        ds = (datasets.SentEvalDataset(path, "multilabel", n_context_sentences=n) if n
+              else datasets.SentDataset(path, "multilabel"))
+        ref, d0, s0 = collate.build_rows(ds, fast.py, n)
+        got, d1, s1 = FT.build_rows_fast(ds, fast, n)
+        assert np.array_equal(got.offsets, ref.offsets), path
+        assert np.array_equal(got.flat, ref.flat), path
+        assert np.array_equal(d0, d1) and np.array_equal(s0, s1)
+        if n and path == paths[2]:
+            assert (ref.lens >= 500).any()          # the trim branch was exercised
+            seps = np.add.reduceat((ref.flat == fast.sep_token_id).astype(np.int64), ref.offsets[:-1])
+            assert (seps == 2 * n + 1).all()        # the invariant bert_model.py:52 needs
