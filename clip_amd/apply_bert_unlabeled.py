@@ -8,13 +8,16 @@ Same positional arguments and flags as the reference (:18-27); MODEL_DIR is a LO
 config.json + vocab.txt (hub short names 'bert' / 'clinicalbert_disch' cannot resolve offline).
 Writes `ttp_doc_sents.csv` next to LOCAL_WEIGHTS exactly as the reference does (:90,97-98,124: no
 header, `doc_id,sent_ix,max_label_score` for rows with any label score > threshold, input order).
+UNLABELED may also be a columnar directory written by an earlier run with `--save_rows DIR` (tokenise
+once — `--tokenize_only` needs no GPU — and score many times; clip_amd/columnar.py).
 With --topk K it also writes `ttp_top{K}.csv` WITH the header `doc_id,sent_ix,max_label_score`, the
 file sentclf/pretrain_tasks.py:37,57-58 reads as `focus_fname` (README.md:43: "sorted by decreasing
 max_label_score ... take the top 250k").
 
-One process per GPU: under `torch.distributed.run` the documents are sharded over ranks
-(topk.shard_documents), every rank scores its shard with no communication, parts are concatenated in
-rank order (= input order) and the top-k uses one all-gather.
+One process per GPU: under `torch.distributed.run` the rows are cut into chunks of whole documents,
+chunk c belongs to rank c mod world, every rank scores its chunks with no communication and keeps a
+running top-k; CSV parts are concatenated in chunk order (= input order) and the top-k uses one
+all-gather.
 """
 import argparse
 import csv
@@ -30,12 +33,16 @@ from .fast_tokenizer import FastWordPiece, build_rows_fast
 from .config import BertConfig
 from .constants import LABEL_TYPES
 from .datasets import SentDataset, SentEvalDataset
-from .scoring import BulkScorer, PackedRows, ScoreResult, write_ttp_csv
+from .columnar import ColumnarCorpus, save_rows
+from .job import RunningTopK, write_topk_csv
+from .scoring import BulkScorer, write_ttp_csv
 
 
 def main(argv=None):
     parser = argparse.ArgumentParser()
-    parser.add_argument("unlabeled_fname", type=str)
+    parser.add_argument("unlabeled_fname", type=str,
+                        help="notes CSV (doc_id, sent_index, sentence[, labels]) or a columnar directory "
+                             "written by --save_rows")
     parser.add_argument("model", type=str, help="local directory with config.json and vocab.txt")
     parser.add_argument("local_weights", type=str,
                         help="state-dict file (.pth / .bin / .safetensors) of the fine-tuned model")
@@ -44,6 +51,11 @@ def main(argv=None):
     parser.add_argument("--task", choices=["binary", "multilabel"], default="multilabel")
     parser.add_argument("--topk", type=int, default=0, help="also write the global top-k file")
     parser.add_argument("--tokens_per_step", type=int, default=65536)
+    parser.add_argument("--chunk_rows", type=int, default=1_000_000,
+                        help="rows scored per chunk of whole documents (bounds host memory; chunk c -> rank c mod world)")
+    parser.add_argument("--save_rows", type=str, default=None,
+                        help="write the tokenised rows as a columnar directory (tokenise once, score many times)")
+    parser.add_argument("--tokenize_only", action="store_true", help="stop after --save_rows (needs no GPU)")
     args = parser.parse_args(argv)
     if args.task != "multilabel":
         raise NotImplementedError("only --task multilabel is on the accelerated path")
@@ -51,6 +63,36 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- rows: a columnar directory as it is, or the CSV through the C++ front end
+    if os.path.isdir(args.unlabeled_fname):
+        corpus = ColumnarCorpus(args.unlabeled_fname)
+        if corpus.meta.get("n_context_sentences") != args.n_context_sentences:
+            raise ValueError(f"{args.unlabeled_fname} was tokenised with n_context_sentences="
+                             f"{corpus.meta.get('n_context_sentences')}, not {args.n_context_sentences}")
+        sep_id = int(corpus.meta["sep_token_id"])
+    else:
+        # C++ WordPiece on all host cores (libclip_tok.so); the Python restatement behind it takes what it flags
+        tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                # :43-47
+        if args.n_context_sentences == 0:                                              # :83-88
+            dataset = SentDataset(args.unlabeled_fname, args.task)
+        else:
+            dataset = SentEvalDataset(args.unlabeled_fname, args.task,
+                                      n_context_sentences=args.n_context_sentences)
+        rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
+        sep_id = tokenizer.sep_token_id
+        meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=sep_id,
+                    cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
+                    source=os.path.basename(args.unlabeled_fname))
+        corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
+        if args.save_rows and rank == 0:
+            save_rows(args.save_rows, rows, doc_ids, sent_ixs, **meta)
+    if args.tokenize_only:
+        if not args.save_rows:
+            raise ValueError("--tokenize_only needs --save_rows")
+        print(f"tokenised {len(corpus)} rows / {corpus.meta['tokens']} tokens -> {args.save_rows}")
+        return None
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -60,8 +102,6 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    # C++ WordPiece on all host cores (libclip_tok.so); the Python restatement behind it takes what it flags
-    tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                   # :43-47
     config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
     model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,
                                                     max_seqs=max(64, args.tokens_per_step // 8))  # :64-70
@@ -73,43 +113,40 @@ def main(argv=None):
     model.load_state_dict(sd)                                                          # :79
     model.to(device).eval()                                                            # :72,100
     if args.n_context_sentences > 0:
-        model.set_sep_token_id(tokenizer.sep_token_id)                                 # :74
+        model.set_sep_token_id(sep_id)                                                 # :74
         model.set_n_context_sentences(args.n_context_sentences)                        # :75
     model.set_task(args.task)                                                          # :80
 
-    if args.n_context_sentences == 0:                                                  # :83-88
-        dataset = SentDataset(args.unlabeled_fname, args.task)
-    else:
-        dataset = SentEvalDataset(args.unlabeled_fname, args.task,
-                                  n_context_sentences=args.n_context_sentences)
-    rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
-    a, b = topk_mod.shard_documents(doc_ids, rows.lens, world, rank)
-    shard = PackedRows(rows.flat[rows.offsets[a]:rows.offsets[b]], rows.offsets[a:b + 1] - rows.offsets[a])
-    res = BulkScorer(model, any_threshold=args.threshold).score(shard, doc_ids[a:b], sent_ixs[a:b])
-
+    # ---- the hot loop (:92-124), chunk by chunk: score, append this chunk's CSV part, fold into the
+    # running top-k.  Chunks are whole documents; chunk c belongs to rank c mod world.
+    scorer = BulkScorer(model, any_threshold=args.threshold)
     out_dir = os.path.dirname(args.local_weights) or "."                               # :90
     out = os.path.join(out_dir, "ttp_doc_sents.csv")
-    part = out if world == 1 else f"{out}.part{rank}"
-    write_ttp_csv(part, res)
+    n_chunks = len(corpus.chunk_bounds(args.chunk_rows))
+    top = RunningTopK(args.topk) if args.topk > 0 else None
+    n_rows = n_kept = 0
+    res = None
+    for c, a, b, (rows_c, d_c, s_c) in corpus.chunks(args.chunk_rows, rank, world):
+        res = scorer.score(rows_c, d_c, s_c)
+        write_ttp_csv(f"{out}.chunk{c}", res)
+        if top is not None:
+            top.update(res.doc_ids, res.sent_ixs, res.max_score, keep=res.keep)
+        n_rows += len(res.keep)
+        n_kept += int(res.keep.sum())
     if dist is not None:
         dist.barrier()
+    if rank == 0:                                       # parts in chunk order = input order (:97-98,124)
+        with open(out, "w") as f:
+            for c in range(n_chunks):
+                with open(f"{out}.chunk{c}") as g:
+                    f.write(g.read())
+                os.remove(f"{out}.chunk{c}")
+    if top is not None:
+        glob = topk_mod.global_topk(top.records, args.topk)
         if rank == 0:
-            with open(out, "w") as f:
-                for r in range(world):
-                    with open(f"{out}.part{r}") as g:
-                        f.write(g.read())
-                    os.remove(f"{out}.part{r}")
-    if args.topk > 0:
-        local = topk_mod.local_topk(res.doc_ids, res.sent_ixs, res.max_score, args.topk, keep=res.keep)
-        top = topk_mod.global_topk(local, args.topk)
-        if rank == 0:
-            with open(os.path.join(out_dir, f"ttp_top{args.topk}.csv"), "w", newline="") as f:
-                w = csv.writer(f)
-                w.writerow(["doc_id", "sent_ix", "max_label_score"])
-                for r in top:
-                    w.writerow([r["doc_id"], r["sent_ix"], r["score"]])
+            write_topk_csv(os.path.join(out_dir, f"ttp_top{args.topk}.csv"), glob)
     if rank == 0:
-        print(f"done! results in {out_dir}  ({int(res.keep.sum())} of {len(res.keep)} sentences selected on rank 0)")
+        print(f"done! results in {out_dir}  ({n_kept} of {n_rows} sentences selected on rank 0)")
     if dist is not None:
         dist.destroy_process_group()
     return res

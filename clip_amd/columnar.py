@@ -1,0 +1,94 @@
+"""Columnar pre-tokenised corpus on disk: tokenise a notes CSV once, score it many times.
+
+The reference re-reads and re-tokenises the CSV on every run, row by row
+(/root/reference/sentclf/apply_bert_unlabeled.py:83-92 -> neural_baselines.py:193-244 -> bert.py:70-188).
+At NOTEEVENTS scale (50 M context rows, ~7 G tokens) the rows do not fit the host's memory as Python
+objects at all.  This is the format the bulk scorer streams instead: a directory of plain .npy files
+
+    flat.npy      int32 [tokens]   every row's ids, concatenated ([CLS] .. [SEP] layout, no padding)
+    offsets.npy   int64 [rows+1]   row i = flat[offsets[i] : offsets[i+1]]
+    doc_ids.npy   int64 [rows]
+    sent_ixs.npy  int64 [rows]
+    meta.json     n_context_sentences, sep/cls ids, vocabulary size, row / token counts
+
+opened with numpy memory maps (nothing is loaded until a chunk is scored) and cut into chunks of WHOLE
+documents — the sharding unit of SURVEY.md §8e: chunk c belongs to rank c mod world, so a sentence's
+context never crosses a rank and the set of chunks does not depend on the world size.
+"""
+import json
+import os
+
+import numpy as np
+
+from .scoring import PackedRows
+
+FILES = ("flat", "offsets", "doc_ids", "sent_ixs")
+
+
+def save_rows(path, rows: PackedRows, doc_ids, sent_ixs, **meta):
+    os.makedirs(path, exist_ok=True)
+    doc_ids = np.asarray(doc_ids, np.int64)
+    sent_ixs = np.asarray(sent_ixs, np.int64)
+    if not (len(rows) == len(doc_ids) == len(sent_ixs)):
+        raise ValueError("rows, doc_ids and sent_ixs differ in length")
+    np.save(os.path.join(path, "flat.npy"), np.ascontiguousarray(rows.flat, np.int32))
+    np.save(os.path.join(path, "offsets.npy"), np.ascontiguousarray(rows.offsets, np.int64))
+    np.save(os.path.join(path, "doc_ids.npy"), doc_ids)
+    np.save(os.path.join(path, "sent_ixs.npy"), sent_ixs)
+    meta = dict(meta, rows=int(len(rows)), tokens=int(rows.offsets[-1]), format="clip_amd.columnar/1")
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+class ColumnarCorpus:
+    @classmethod
+    def from_arrays(cls, rows: PackedRows, doc_ids, sent_ixs, **meta):
+        """The same interface over rows already in memory (a CSV tokenised in this process)."""
+        self = cls.__new__(cls)
+        self.flat, self.offsets = rows.flat, rows.offsets
+        self.doc_ids, self.sent_ixs = np.asarray(doc_ids, np.int64), np.asarray(sent_ixs, np.int64)
+        self.meta = dict(meta, rows=len(rows), tokens=int(rows.offsets[-1]), format="clip_amd.columnar/1")
+        return self
+
+    def __init__(self, path, mmap=True):
+        mode = "r" if mmap else None
+        for k in FILES:
+            setattr(self, k, np.load(os.path.join(path, k + ".npy"), mmap_mode=mode))
+        with open(os.path.join(path, "meta.json")) as f:
+            self.meta = json.load(f)
+        n = len(self.doc_ids)
+        if self.meta.get("format") != "clip_amd.columnar/1" or len(self.offsets) != n + 1 or len(self.sent_ixs) != n \
+                or int(self.offsets[-1]) != len(self.flat):
+            raise ValueError(f"{path}: not a consistent clip_amd columnar corpus")
+
+    def __len__(self):
+        return len(self.doc_ids)
+
+    def slice(self, a, b):
+        """rows [a, b) as (PackedRows, doc_ids, sent_ixs), copied out of the memory map."""
+        o = np.asarray(self.offsets[a:b + 1])
+        return (PackedRows(np.asarray(self.flat[o[0]:o[-1]]), o - o[0]), np.asarray(self.doc_ids[a:b]),
+                np.asarray(self.sent_ixs[a:b]))
+
+    def chunk_bounds(self, chunk_rows):
+        """Row ranges of about chunk_rows rows that end on document boundaries (rows of a document are
+        contiguous, as in the reference's CSVs).  A document longer than chunk_rows is one chunk."""
+        n = len(self)
+        if n == 0:
+            return []
+        d = np.asarray(self.doc_ids)
+        starts = np.concatenate(([0], np.flatnonzero(d[1:] != d[:-1]) + 1, [n]))     # first row of each document, then n
+        bounds, a = [], 0
+        while a < n:
+            k = int(np.searchsorted(starts, a + chunk_rows, side="right")) - 1      # last boundary <= a + chunk_rows
+            b = int(starts[k])
+            if b <= a:                                                               # one long document
+                b = int(starts[int(np.searchsorted(starts, a, side="right"))])
+            bounds.append((a, b))
+            a = b
+        return bounds
+
+    def chunks(self, chunk_rows, rank=0, world=1):
+        for c, (a, b) in enumerate(self.chunk_bounds(chunk_rows)):
+            if c % world == rank:
+                yield c, a, b, self.slice(a, b)

@@ -1,0 +1,54 @@
+"""Columnar pre-tokenised corpus (clip_amd/columnar.py): round trip through memory-mapped .npy files
+and chunking at document boundaries."""
+import numpy as np
+import pytest
+
+from clip_amd import columnar, synth
+from clip_amd.scoring import PackedRows
+
+
+def _corpus(n=5000, seed=4):
+    flat, off = synth.packed_context_rows(n, 2, 3000, 128, seed=seed)
+    d, s = synth.documents(n, seed=seed, lo=1, hi=60)
+    return PackedRows(flat, off), d, s.astype(np.int64)
+
+
+def test_round_trip_and_chunks(tmp_path):
+    rows, d, s = _corpus()
+    columnar.save_rows(str(tmp_path / "c"), rows, d, s, n_context_sentences=2, sep_token_id=102)
+    c = columnar.ColumnarCorpus(str(tmp_path / "c"))
+    assert len(c) == len(rows) and c.meta["tokens"] == int(rows.offsets[-1]) and c.meta["n_context_sentences"] == 2
+    assert isinstance(c.flat, np.memmap)
+    bounds = c.chunk_bounds(300)
+    assert bounds[0][0] == 0 and bounds[-1][1] == len(rows)
+    assert all(a1 == b0 for (_, b0), (a1, _) in zip(bounds, bounds[1:]))            # a partition
+    for a, b in bounds:
+        assert b > a and (b == len(rows) or d[b] != d[b - 1])                        # ends on a document boundary
+        assert b - a <= 300 or len(set(d[a:b])) == 1                                 # only a long document exceeds it
+    # every rank's chunks together = the corpus, each row once, contents intact
+    seen = np.zeros(len(rows), int)
+    for world in (1, 3):
+        seen[:] = 0
+        for rank in range(world):
+            for ci, a, b, (r, dd, ss) in c.chunks(300, rank, world):
+                assert ci % world == rank
+                seen[a:b] += 1
+                assert np.array_equal(r.flat, rows.flat[rows.offsets[a]:rows.offsets[b]])
+                assert np.array_equal(r.offsets, rows.offsets[a:b + 1] - rows.offsets[a])
+                assert np.array_equal(dd, d[a:b]) and np.array_equal(ss, s[a:b])
+        assert (seen == 1).all()
+    mem = columnar.ColumnarCorpus.from_arrays(rows, d, s)
+    assert mem.chunk_bounds(300) == bounds
+
+
+def test_one_long_document_and_bad_directory(tmp_path):
+    rows, d, s = _corpus(400)
+    d[:] = 7
+    c = columnar.ColumnarCorpus.from_arrays(rows, d, s)
+    assert c.chunk_bounds(50) == [(0, 400)]
+    columnar.save_rows(str(tmp_path / "c"), rows, d, s)
+    np.save(str(tmp_path / "c" / "sent_ixs.npy"), s[:-1])
+    with pytest.raises(ValueError):
+        columnar.ColumnarCorpus(str(tmp_path / "c"))
+    with pytest.raises(ValueError):
+        columnar.save_rows(str(tmp_path / "d"), rows, d[:-1], s)

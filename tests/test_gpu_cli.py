@@ -80,3 +80,30 @@ def test_cli_matches_oracle(tmp_path, n_ctx):
     assert rows[0] == ["doc_id", "sent_ix", "max_label_score"] and len(rows) == 11
     sc = [float(r[2]) for r in rows[1:]]
     assert sc == sorted(sc, reverse=True)
+
+
+def test_cli_columnar_round_trip_and_chunking(tmp_path):
+    """Tokenise once (--save_rows, --tokenize_only), score from the columnar directory in small chunks:
+    byte-identical files to the one-shot CSV run."""
+    cfg = BertConfig(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=512)
+    model_dir = tmp_path / "model"
+    cfg.save_pretrained(str(model_dir))
+    shutil.copyfile(os.path.join(G, "vocab.txt"), model_dir / "vocab.txt")
+    sd = procedural_state_dict(cfg, 31)
+    outs = []
+    path = os.path.join(G, "notes_synth.csv")
+    rows_dir = tmp_path / "rows"
+    apply_bert_unlabeled.main([path, str(model_dir), "unused.pth", "--n_context_sentences", "2",
+                               "--save_rows", str(rows_dir), "--tokenize_only"])
+    for name, src, extra in (("csv", path, []), ("col", str(rows_dir), ["--chunk_rows", "7"])):
+        run_dir = tmp_path / name
+        run_dir.mkdir()
+        torch.save(sd, run_dir / "w.pth")
+        apply_bert_unlabeled.main([src, str(model_dir), str(run_dir / "w.pth"), "--n_context_sentences", "2",
+                                   "--threshold", "0.5", "--topk", "10", "--tokens_per_step", "4096"] + extra)
+        outs.append((open(run_dir / "ttp_doc_sents.csv").read(), open(run_dir / "ttp_top10.csv").read()))
+        assert not [f for f in os.listdir(run_dir) if ".chunk" in f]
+    assert outs[0] == outs[1] and len(outs[0][0]) > 0
+    with pytest.raises(ValueError):
+        apply_bert_unlabeled.main([str(rows_dir), str(model_dir), "w.pth", "--n_context_sentences", "1"])
