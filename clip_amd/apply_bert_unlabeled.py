@@ -50,7 +50,7 @@ def main(argv=None):
     parser.add_argument("--n_context_sentences", type=int, default=0)
     parser.add_argument("--task", choices=["binary", "multilabel"], default="multilabel")
     parser.add_argument("--topk", type=int, default=0, help="also write the global top-k file")
-    parser.add_argument("--tokens_per_step", type=int, default=65536)
+    parser.add_argument("--tokens_per_step", type=int, default=131072)
     parser.add_argument("--chunk_rows", type=int, default=1_000_000,
                         help="rows scored per chunk of whole documents (bounds host memory; chunk c -> rank c mod world)")
     parser.add_argument("--save_rows", type=str, default=None,

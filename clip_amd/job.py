@@ -94,7 +94,7 @@ def main(argv=None):
     ap.add_argument("--chunk-rows", type=int, default=250_000)
     ap.add_argument("--topk", type=int, default=250_000)
     ap.add_argument("--threshold", type=float, default=0.05)
-    ap.add_argument("--tokens-per-step", type=int, default=65536)
+    ap.add_argument("--tokens-per-step", type=int, default=131072)
     ap.add_argument("--weights", type=str, default=None, help="state dict (.safetensors); default: procedural")
     ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
     args = ap.parse_args(argv)
