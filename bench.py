@@ -77,10 +77,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        # backend "nccl" IS RCCL on ROCm.  CLIP_DIST_BACKEND=gloo is for rehearsing the multi-rank code
+        # path on a box with fewer GPUs than ranks (ranks then share a card: functional check only)
+        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     cfg = BertConfig()
     n_ctx = 2
@@ -141,7 +145,7 @@ def main():
     _lib.check(lib.clip_profile_read(engine, ms, cnt, 1))
     _lib.check(lib.clip_profile_enable(engine, 0))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

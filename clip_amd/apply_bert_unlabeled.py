@@ -97,10 +97,12 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")     # "gloo": rehearsal on fewer GPUs than ranks
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
     model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,

@@ -175,6 +175,10 @@ class _EngineModel:
             for k, v in self._sd.items():
                 _lib.check(lib.clip_load_weight(h, k.encode(), C.c_void_p(v.data_ptr()), v.numel()))
             _lib.check(lib.clip_finalize_weights(h))
+            if os.environ.get("CLIP_AMD_FUSED_LN", "1") == "0":
+                # the fused-LayerNorm GEMMs exchange row sums between co-resident workgroups: on a GPU
+                # shared with other processes run the unfused flow (same results to the last few ulps)
+                _lib.check(lib.clip_set_fused_layernorm(h, 0))
         except Exception:
             lib.clip_destroy(h)
             raise

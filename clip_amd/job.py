@@ -106,10 +106,12 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")     # "gloo": rehearsal on fewer GPUs than ranks
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     cfg = BertConfig()
     n_ctx = CONFIGS[args.config][0]
@@ -142,7 +144,8 @@ def main(argv=None):
     glob = topk.global_topk(top.records, args.topk)
     barrier()
     t_all = time.perf_counter() - t0
-    tot = torch.tensor([rows_done, tokens, kept], dtype=torch.int64, device=device)
+    tot = torch.tensor([rows_done, tokens, kept], dtype=torch.int64,
+                       device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tot)
     if rank == 0:
