@@ -46,6 +46,15 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 #ifndef GEMM8_STORE
 #define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
 #endif
+// diagnostic builds (-DLNOUT_STAMPS, tools/lnout_stamps.py): wave 0 of every workgroup stamps its second
+// tile's fused-LayerNorm epilogue with s_memtime into lo.err[64 + 8 blockIdx.x + k]; no output depends on it
+#ifdef LNOUT_STAMPS
+#define LN_STAMP(k)                                                                              \
+  if (EPI == EPI_BIAS_LNOUT && it == 1 && tid == 0)                                              \
+    reinterpret_cast<volatile uint32_t*>(lo.err)[64 + 8 * blockIdx.x + (k)] = (uint32_t)__builtin_amdgcn_s_memtime();
+#else
+#define LN_STAMP(k)
+#endif
 template <typename V>
 __device__ __forceinline__ void out_store(V v, V* p) {
   if (GEMM8_STORE == 0) __builtin_nontemporal_store(v, p);
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[mh][nh][m][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4..7 run one barrier behind
+    LN_STAMP(0)
 
     bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
     for (int kk = 0; kk < nt; kk += 2) {
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       ktile.template operator()<1>();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balances the extra barrier of waves 4..7
+    LN_STAMP(1)
 
     // ---- epilogue: 16-row passes through this wave's scratch, whole 128-byte row segments out
     const int n_base = tn * BN + wc * 64;
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               }
           }
       }
+      LN_STAMP(2)
       // (2) per-row (sum, sum of squares) over this wave's 64 columns -> LDS, one slot per column wave
       float2* part_lds = reinterpret_cast<float2*>(smem + RING);                       // [4][256], in the scratch
       float2* tot_lds = reinterpret_cast<float2*>(smem + RING + 8 * SCR + 2 * 3072);   // [256] this tile's sums
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           if (fq == 0) part_lds[wc * 256 + mh * 128 + wr * 64 + m * 16 + fr] = make_float2(sm, sq);
         }
       __syncthreads();
+      LN_STAMP(3)
       // (3) the workgroup's 256-column partial per row: published write-through (sc1 stores, every
       // storing wave drained, barrier), then the flag (MI355X_MICROARCH.md, inter-workgroup hand-off)
       const int tile_id = tm * tiles_n + tn;
@@ -364,6 +377,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(lo.flags + tile_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      LN_STAMP(4)
       // (4) wait for the other column tiles of this row panel (lane 0 of wave k polls tile k), bounded:
       // the partners are resident and one tile-time away at most, unless the GPU is shared
 #ifndef LNOUT_NOSYNC  // diagnostic builds
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       }
 #endif
       __syncthreads();
+      LN_STAMP(5)
       if (tid < 256) {
         float2 T = make_float2(0.f, 0.f);
         for (int k = 0; k < tiles_n; ++k) {  // fixed order: every tile of the panel gets the same bits
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         stat_lds[tid] = make_float2(mean, 1.0f / sqrtf(var + lo.eps));
       }
       __syncthreads();
+      LN_STAMP(6)
       // (5) normalise in registers; the fp16 residual copy goes out tiled straight from the registers
       // (1-KiB wave stores), the bf16 GEMM operand through the transpose scratch as whole row segments
       const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + fq * 4;
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                       reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(out) + (m0 + row) * ldo + n_base + c16 * 8));
           }
         }
+      LN_STAMP(7)
     } else if (!OUT_F32) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
