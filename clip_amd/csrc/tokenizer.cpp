@@ -1,14 +1,18 @@
 // libclip_tok.so — host-side WordPiece front end (include/clip_tok.h).  Plain C++20, no GPU code.
 //
-// Restates, for 7-bit ASCII text, what the reference's tokenizer call does per sentence
-// (/root/reference/sentclf/bert.py:57,105,152 -> HF BertTokenizer): BertNormalizer (drop NUL and
-// control characters, whitespace -> ' ', lower-case; accent stripping and CJK spacing cannot apply to
-// ASCII), BertPreTokenizer (split on whitespace, every punctuation character its own word), greedy
+// Restates what the reference's tokenizer call does per sentence (/root/reference/sentclf/bert.py:57,
+// 105,152 -> HF BertTokenizer): BertNormalizer (drop NUL, U+FFFD and control characters, whitespace ->
+// ' ', spaces around CJK ideographs, and when lower-casing: NFD, drop nonspacing marks, lower-case),
+// BertPreTokenizer (split on whitespace, every punctuation character its own word), greedy
 // longest-match WordPiece ("##" continuations, words over 100 characters -> [UNK]) — and, in
 // CLIP_TOK_LIST_CELL mode, the `eval(row.sentence)` + ' '.join + .lower() of
-// sentclf/neural_baselines.py:197-201 / bert.py:100 on the CSV cell itself.  Anything outside that
-// scope (a byte >= 0x80, list-literal syntax beyond plain quoted strings) is flagged for the
-// caller's Python restatement (clip_amd/wordpiece.py), never guessed at.
+// sentclf/neural_baselines.py:197-201 / bert.py:100 on the CSV cell itself.
+// Pure-ASCII strings (MIMIC notes) take a byte path; other strings take a code-point path over tables
+// generated from Python's unicodedata (unicode_tables.h, tools/gen_unicode_tables.py) — the source the
+// Python restatement consults.  What is still outside the scope is flagged for that restatement
+// (clip_amd/wordpiece.py), never guessed at: capital sigma (its lower case depends on context), invalid
+// UTF-8, list-literal syntax beyond plain quoted strings, and every non-ASCII string when the caller
+// says its Unicode tables are of another version (CLIP_TOK_ASCII_ONLY).
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -21,6 +25,7 @@
 #include <vector>
 
 #include "../../include/clip_tok.h"
+#include "unicode_tables.h"
 
 namespace {
 
@@ -75,7 +80,9 @@ struct WordCache {
   std::vector<int32_t> pool;
 };
 
-void wordpiece(const clip_tokenizer& t, std::string_view word, WordCache& cache, std::vector<int32_t>& out) {
+// `bounds` (ncp + 1 byte offsets of the code points) is null for ASCII words: byte = character
+void wordpiece(const clip_tokenizer& t, std::string_view word, WordCache& cache, std::vector<int32_t>& out,
+               const uint32_t* bounds = nullptr, size_t ncp = 0) {
   auto hit = cache.map.find(word);
   if (hit != cache.map.end()) {
     out.insert(out.end(), cache.pool.begin() + hit->second.first,
@@ -83,25 +90,28 @@ void wordpiece(const clip_tokenizer& t, std::string_view word, WordCache& cache,
     return;
   }
   const size_t first = out.size();
-  const size_t n = word.size();
+  const size_t n = bounds ? ncp : word.size();
+  auto at = [&](size_t i) -> size_t { return bounds ? bounds[i] : i; };
   if ((int)n > t.max_chars) {
     out.push_back(t.special[1]);
   } else {
-    char buf[128];   // "##" + at most max_chars bytes
-    buf[0] = buf[1] = '#';
+    std::string buf = "##";
     size_t start = 0;
     bool bad = false;
     while (start < n) {
       const size_t pre = start > 0 ? 2 : 0;
-      size_t end = std::min(n, start + (t.max_piece > pre ? t.max_piece - pre : 0));
+      size_t end = n;
       int32_t cur = -1;
       for (; end > start; --end) {
+        const size_t len = at(end) - at(start);
+        if (len + pre > t.max_piece) continue;       // longer than every vocabulary entry
         std::string_view sub;
         if (pre) {
-          memcpy(buf + 2, word.data() + start, end - start);
-          sub = std::string_view(buf, 2 + end - start);
+          buf.resize(2);
+          buf.append(word.data() + at(start), len);
+          sub = buf;
         } else {
-          sub = word.substr(0, end);
+          sub = word.substr(0, len);
         }
         auto it = t.vocab.find(sub);
         if (it != t.vocab.end()) { cur = it->second; break; }
@@ -119,6 +129,184 @@ void wordpiece(const clip_tokenizer& t, std::string_view word, WordCache& cache,
   const uint32_t off = (uint32_t)cache.pool.size(), len = (uint32_t)(out.size() - first);
   cache.pool.insert(cache.pool.end(), out.begin() + first, out.end());
   cache.map.emplace(std::string(word), std::make_pair(off, len));
+}
+
+// ---------------------------------------------------------------- code-point path (non-ASCII text)
+bool in_ranges(const uint32_t (*r)[2], int n, uint32_t cp) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cp < r[mid][0]) hi = mid - 1;
+    else if (cp > r[mid][1]) lo = mid + 1;
+    else return true;
+  }
+  return false;
+}
+uint32_t ccc_of(uint32_t cp) {
+  int lo = 0, hi = UC_CCC_N - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cp < UC_CCC[mid][0]) hi = mid - 1;
+    else if (cp > UC_CCC[mid][1]) lo = mid + 1;
+    else return UC_CCC[mid][2];
+  }
+  return 0;
+}
+template <int W>
+const uint32_t* find_cp(const uint32_t (*tab)[W], int n, uint32_t cp) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cp < tab[mid][0]) hi = mid - 1;
+    else if (cp > tab[mid][0]) lo = mid + 1;
+    else return tab[mid];
+  }
+  return nullptr;
+}
+inline bool is_cjk(uint32_t cp) {
+  return (cp >= 0x4E00 && cp <= 0x9FFF) || (cp >= 0x3400 && cp <= 0x4DBF) || (cp >= 0x20000 && cp <= 0x2A6DF) ||
+         (cp >= 0x2A700 && cp <= 0x2B73F) || (cp >= 0x2B740 && cp <= 0x2B81F) || (cp >= 0x2B820 && cp <= 0x2CEAF) ||
+         (cp >= 0xF900 && cp <= 0xFAFF) || (cp >= 0x2F800 && cp <= 0x2FA1F);
+}
+inline bool u_dropped(uint32_t cp) { return cp < 0x80 ? is_dropped((unsigned char)cp) : in_ranges(UC_DROP, UC_DROP_N, cp); }
+inline bool u_white(uint32_t cp) { return cp < 0x80 ? is_space((unsigned char)cp) : in_ranges(UC_ZS, UC_ZS_N, cp); }
+inline bool u_isspace(uint32_t cp) {   // str.isspace()
+  return cp < 0x80 ? (cp == ' ' || (cp >= 9 && cp <= 13) || (cp >= 0x1c && cp <= 0x1f)) : in_ranges(UC_ISSPACE, UC_ISSPACE_N, cp);
+}
+inline bool u_punct(uint32_t cp) { return cp < 0x80 ? is_punct((unsigned char)cp) : in_ranges(UC_PUNCT, UC_PUNCT_N, cp); }
+
+bool decode_utf8(const char* s, size_t n, std::vector<uint32_t>& out) {
+  out.clear();
+  size_t i = 0;
+  while (i < n) {
+    const unsigned char c = (unsigned char)s[i];
+    uint32_t cp;
+    int extra;
+    if (c < 0x80) { cp = c; extra = 0; }
+    else if ((c & 0xE0) == 0xC0) { cp = c & 0x1F; extra = 1; }
+    else if ((c & 0xF0) == 0xE0) { cp = c & 0x0F; extra = 2; }
+    else if ((c & 0xF8) == 0xF0) { cp = c & 0x07; extra = 3; }
+    else return false;
+    for (int k = 1; k <= extra; ++k) {
+      if (i + k >= n) return false;
+      const unsigned char d = (unsigned char)s[i + k];
+      if ((d & 0xC0) != 0x80) return false;
+      cp = (cp << 6) | (d & 0x3F);
+    }
+    static const uint32_t min_cp[4] = {0, 0x80, 0x800, 0x10000};
+    if (cp < min_cp[extra] || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+    out.push_back(cp);
+    i += extra + 1;
+  }
+  return true;
+}
+void append_utf8(std::string& s, uint32_t cp) {
+  if (cp < 0x80) s.push_back((char)cp);
+  else if (cp < 0x800) { s.push_back((char)(0xC0 | (cp >> 6))); s.push_back((char)(0x80 | (cp & 0x3F))); }
+  else if (cp < 0x10000) {
+    s.push_back((char)(0xE0 | (cp >> 12))); s.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); s.push_back((char)(0x80 | (cp & 0x3F)));
+  } else {
+    s.push_back((char)(0xF0 | (cp >> 18))); s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+    s.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); s.push_back((char)(0x80 | (cp & 0x3F)));
+  }
+}
+
+// str.lower() of a code-point string; false when it holds a capital sigma (context-dependent)
+bool lower_cps(const std::vector<uint32_t>& in, std::vector<uint32_t>& out) {
+  out.clear();
+  for (uint32_t cp : in) {
+    if (cp == 0x3A3) return false;
+    if (cp < 0x80) { out.push_back((cp >= 'A' && cp <= 'Z') ? cp + 32 : cp); continue; }
+    if (const uint32_t* m = find_cp<5>(UC_LOWER_MULTI, UC_LOWER_MULTI_N, cp)) {
+      for (uint32_t k = 0; k < m[1]; ++k) out.push_back(m[2 + k]);
+      continue;
+    }
+    const uint32_t* l = find_cp<2>(UC_LOWER, UC_LOWER_N, cp);
+    out.push_back(l ? l[1] : cp);
+  }
+  return true;
+}
+
+struct UScratch {
+  std::vector<uint32_t> a, b, word;
+  std::vector<uint32_t> bounds;
+  std::string bytes;
+};
+
+// normalise + pre-tokenise + WordPiece one run given as code points; false = leave to the caller
+bool encode_run_u(const clip_tokenizer& t, const std::vector<uint32_t>& cps, bool lower, WordCache& cache,
+                  UScratch& u, std::vector<int32_t>& out) {
+  std::vector<uint32_t>& a = u.a;
+  std::vector<uint32_t>& b = u.b;
+  a.clear();
+  for (uint32_t cp : cps) {                                  // clean text + CJK spacing
+    if (cp == 0 || cp == 0xFFFD || u_dropped(cp)) continue;
+    if (u_white(cp)) { a.push_back(' '); continue; }
+    if (is_cjk(cp)) { a.push_back(' '); a.push_back(cp); a.push_back(' '); }
+    else a.push_back(cp);
+  }
+  if (lower) {
+    b.clear();
+    for (uint32_t cp : a) {                                  // NFD: full canonical decomposition ...
+      if (cp >= 0xAC00 && cp <= 0xD7A3) {                    // Hangul syllables, algorithmically
+        const uint32_t si = cp - 0xAC00, tj = si % 28;
+        b.push_back(0x1100 + si / 588);
+        b.push_back(0x1161 + (si % 588) / 28);
+        if (tj) b.push_back(0x11A7 + tj);
+      } else if (cp < 0xC0) {
+        b.push_back(cp);
+      } else if (const uint32_t* d = find_cp<3>(UC_NFD_IDX, UC_NFD_IDX_N, cp)) {
+        for (uint32_t k = 0; k < d[2]; ++k) b.push_back(UC_NFD_DATA[d[1] + k]);
+      } else {
+        b.push_back(cp);
+      }
+    }
+    for (size_t i = 1; i < b.size(); ++i) {                  // ... in canonical order (stable by class)
+      const uint32_t ci = b[i] < 0x300 ? 0 : ccc_of(b[i]);
+      if (!ci) continue;
+      size_t j = i;
+      while (j > 0) {
+        const uint32_t cj = b[j - 1] < 0x300 ? 0 : ccc_of(b[j - 1]);
+        if (cj <= ci) break;                                 // cj == 0 is a starter: stop
+        std::swap(b[j], b[j - 1]);
+        --j;
+      }
+    }
+    a.clear();
+    for (uint32_t cp : b)                                    // strip accents
+      if (cp < 0x300 || !in_ranges(UC_MN, UC_MN_N, cp)) a.push_back(cp);
+    if (!lower_cps(a, b)) return false;
+    a.swap(b);
+  }
+  auto flush = [&]() {
+    if (u.word.empty()) return;
+    u.bytes.clear();
+    u.bounds.clear();
+    bool ascii = true;
+    for (uint32_t cp : u.word) {
+      u.bounds.push_back((uint32_t)u.bytes.size());
+      append_utf8(u.bytes, cp);
+      ascii = ascii && cp < 0x80;
+    }
+    u.bounds.push_back((uint32_t)u.bytes.size());
+    if (ascii) wordpiece(t, u.bytes, cache, out);
+    else wordpiece(t, u.bytes, cache, out, u.bounds.data(), u.word.size());
+    u.word.clear();
+  };
+  u.word.clear();
+  for (uint32_t cp : a) {
+    if (u_isspace(cp)) flush();
+    else if (u_punct(cp)) { flush(); u.word.push_back(cp); flush(); }
+    else u.word.push_back(cp);
+  }
+  flush();
+  return true;
+}
+
+inline bool all_ascii(const char* s, size_t n) {
+  for (size_t k = 0; k < n; ++k)
+    if ((unsigned char)s[k] >= 0x80) return false;
+  return true;
 }
 
 // normalise + pre-tokenise + WordPiece one run of ASCII text (no special tokens inside)
@@ -141,9 +329,20 @@ void encode_run(const clip_tokenizer& t, const char* s, size_t n, bool lower, Wo
   if (!word.empty()) { wordpiece(t, word, cache, out); word.clear(); }
 }
 
+// one run of text without special tokens: byte path when it is ASCII, code-point path otherwise
+bool encode_any_run(const clip_tokenizer& t, const char* s, size_t n, bool ascii_only, WordCache& cache,
+                    std::string& word, UScratch& u, std::vector<uint32_t>& cps, std::vector<int32_t>& out) {
+  if (all_ascii(s, n)) {
+    encode_run(t, s, n, t.lower, cache, word, out);
+    return true;
+  }
+  if (ascii_only || !decode_utf8(s, n, cps)) return false;
+  return encode_run_u(t, cps, t.lower, cache, u, out);
+}
+
 // CLIP_TOK_TEXT: literal special tokens are cut out first, as HF's added-token matching does
-void encode_text(const clip_tokenizer& t, const char* s, size_t n, WordCache& cache, std::string& word,
-                 std::vector<int32_t>& out) {
+bool encode_text(const clip_tokenizer& t, const char* s, size_t n, bool ascii_only, WordCache& cache,
+                 std::string& word, UScratch& u, std::vector<uint32_t>& cps, std::vector<int32_t>& out) {
   size_t run = 0, i = 0;
   while (i < n) {
     if (s[i] == '[') {
@@ -153,7 +352,7 @@ void encode_text(const clip_tokenizer& t, const char* s, size_t n, WordCache& ca
         if (i + L <= n && memcmp(s + i, SPECIALS[k], L) == 0) { which = k; break; }
       }
       if (which >= 0) {
-        encode_run(t, s + run, i - run, t.lower, cache, word, out);
+        if (!encode_any_run(t, s + run, i - run, ascii_only, cache, word, u, cps, out)) return false;
         out.push_back(t.special[which]);
         i += strlen(SPECIALS[which]);
         run = i;
@@ -162,7 +361,7 @@ void encode_text(const clip_tokenizer& t, const char* s, size_t n, WordCache& ca
     }
     ++i;
   }
-  encode_run(t, s + run, n - run, t.lower, cache, word, out);
+  return encode_any_run(t, s + run, n - run, ascii_only, cache, word, u, cps, out);
 }
 
 // CLIP_TOK_LIST_CELL: "['Pt', 'should', \"don't\"]" -> "Pt should don't".  Returns false when the cell
@@ -220,25 +419,31 @@ struct Chunk {
 void run_chunk(const clip_tokenizer& t, const char* blob, const int64_t* off, int64_t a, int64_t b, int mode,
                uint8_t* fallback, Chunk& ch) {
   WordCache cache;
+  UScratch u;
+  std::vector<uint32_t> cps, low;
   std::string word, text;
+  const bool ascii_only = (mode & CLIP_TOK_ASCII_ONLY) != 0;
+  const int base = mode & 0xff;
   ch.lens.resize(b - a);
   for (int64_t i = a; i < b; ++i) {
     const char* s = blob + off[i];
     const size_t n = (size_t)(off[i + 1] - off[i]);
     const size_t before = ch.ids.size();
-    bool ascii = true;
-    for (size_t k = 0; k < n; ++k)
-      if ((unsigned char)s[k] >= 0x80) { ascii = false; break; }
-    bool ok = ascii;
-    if (ok) {
-      if (mode == CLIP_TOK_LIST_CELL) {
-        ok = parse_list_cell(s, n, text);
-        // .lower() precedes the tokenizer call (bert.py:100), so "[SEP]" inside a sentence is
-        // "[sep]" by then: plain text, no special-token matching
-        if (ok) encode_run(t, text.data(), text.size(), true, cache, word, ch.ids);
-      } else {
-        encode_text(t, s, n, cache, word, ch.ids);
+    bool ok;
+    if (base == CLIP_TOK_LIST_CELL) {
+      // .lower() precedes the tokenizer call (bert.py:100), so "[SEP]" inside a sentence is "[sep]" by
+      // then: plain text, no special-token matching
+      ok = (!ascii_only || all_ascii(s, n)) && parse_list_cell(s, n, text);
+      if (ok) {
+        if (all_ascii(text.data(), text.size())) {
+          encode_run(t, text.data(), text.size(), true, cache, word, ch.ids);
+        } else {
+          ok = decode_utf8(text.data(), text.size(), cps) && lower_cps(cps, low) &&
+               encode_run_u(t, low, t.lower, cache, u, ch.ids);
+        }
       }
+    } else {
+      ok = encode_text(t, s, n, ascii_only, cache, word, u, cps, ch.ids);
     }
     fallback[i] = ok ? 0 : 1;
     if (!ok) ch.ids.resize(before);
@@ -251,6 +456,7 @@ void run_chunk(const clip_tokenizer& t, const char* blob, const int64_t* off, in
 extern "C" {
 
 const char* clip_tok_last_error(void) { return g_err.c_str(); }
+const char* clip_tok_unicode_version(void) { return UC_VERSION; }
 
 int clip_tok_create(const char* vocab_path, int32_t do_lower_case, clip_tokenizer** out) {
   if (!vocab_path || !out) return fail(CLIP_TOK_ERR_ARG, "clip_tok_create: null argument");
@@ -298,7 +504,7 @@ int clip_tok_encode_plain(clip_tokenizer* t, const char* blob, const int64_t* of
                           int32_t n_threads, int32_t* ids, int64_t ids_cap, int64_t* ids_off, uint8_t* fallback) {
   if (!t || !off || !ids_off || !fallback || n < 0 || (n > 0 && (!blob || !ids)))
     return fail(CLIP_TOK_ERR_ARG, "clip_tok_encode_plain: null argument");
-  if (mode != CLIP_TOK_TEXT && mode != CLIP_TOK_LIST_CELL)
+  if ((mode & ~CLIP_TOK_ASCII_ONLY) != CLIP_TOK_TEXT && (mode & ~CLIP_TOK_ASCII_ONLY) != CLIP_TOK_LIST_CELL)
     return fail(CLIP_TOK_ERR_ARG, "clip_tok_encode_plain: unknown mode %d", mode);
   for (int64_t i = 0; i < n; ++i)
     if (off[i + 1] < off[i]) return fail(CLIP_TOK_ERR_ARG, "clip_tok_encode_plain: offsets decrease at %lld", (long long)i);

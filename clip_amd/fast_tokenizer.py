@@ -24,7 +24,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLIP_TOK_LIB") or os.path.join(_HERE, "lib", "libclip_tok.so")
-MODE_TEXT, MODE_LIST_CELL = 0, 1
+MODE_TEXT, MODE_LIST_CELL, MODE_ASCII_ONLY = 0, 1, 256
 
 _p, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SIGNATURES = {
@@ -34,6 +34,7 @@ SIGNATURES = {
     "clip_tok_special_ids": [_p, _p],
     "clip_tok_encode_plain": [_p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p],
     "clip_tok_last_error": [],
+    "clip_tok_unicode_version": [],
 }
 _lib = None
 
@@ -49,7 +50,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_char_p if name == "clip_tok_last_error" else C.c_int
+        fn.restype = C.c_char_p if name in ("clip_tok_last_error", "clip_tok_unicode_version") else C.c_int
     _lib = lib
     return lib
 
@@ -84,6 +85,10 @@ class FastWordPiece:
         self.py = BertWordPieceTokenizer(vocab_file, do_lower_case=do_lower_case)
         self.n_threads = int(n_threads or min(16, os.cpu_count() or 1))
         lib = load()
+        import unicodedata
+        # the library's tables and this interpreter's unicodedata must be the same Unicode version for the
+        # two to agree on every code point; otherwise non-ASCII strings stay with the Python restatement
+        self.mode_flags = 0 if lib.clip_tok_unicode_version().decode() == unicodedata.unidata_version else MODE_ASCII_ONLY
         h = C.c_void_p()
         _check(lib.clip_tok_create(os.fsencode(vocab_file), int(do_lower_case), C.byref(h)))
         self._h = h
@@ -112,7 +117,7 @@ class FastWordPiece:
         ids = np.empty(cap, np.int32)
         ids_off = np.empty(n + 1, np.int64)
         fb = np.zeros(max(n, 1), np.uint8)
-        _check(load().clip_tok_encode_plain(self._h, _np_ptr(blob), _np_ptr(off), n, mode, self.n_threads,
+        _check(load().clip_tok_encode_plain(self._h, _np_ptr(blob), _np_ptr(off), n, mode | self.mode_flags, self.n_threads,
                                             _np_ptr(ids), cap, _np_ptr(ids_off), _np_ptr(fb)))
         del keep
         fb = fb[:n].astype(bool)

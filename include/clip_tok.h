@@ -9,12 +9,15 @@
  * The reference binds HF `tokenizers` (a Rust extension) through Python; the binding a maintainer
  * adds for this library is the ctypes stub in INTEGRATION.md §4 (clip_amd/fast_tokenizer.py).
  *
- * Scope: the FAST PATH only — 7-bit ASCII text (MIMIC notes are ASCII), where BertNormalizer +
- * BertPreTokenizer + WordPiece reduce to byte operations.  A string holding any byte >= 0x80, or a
- * list literal using syntax beyond plain quoted strings, is NOT tokenised: its `fallback` flag is
- * set and the caller runs the Python restatement (clip_amd/wordpiece.py, pinned by goldens from HF's
- * tokenizer) on that one string.  Results of the fast path are bit-identical to that restatement
- * (tests/test_fast_tokenizer.py).
+ * Scope: pure-ASCII strings (MIMIC notes are ASCII) take a byte path; other strings take a code-point
+ * path (NFD, nonspacing marks dropped, lower-casing, Unicode whitespace / punctuation / CJK rules) over
+ * tables generated from Python's unicodedata (clip_amd/csrc/unicode_tables.h).  What stays outside is
+ * never guessed at: its `fallback` flag is set and the caller runs the Python restatement
+ * (clip_amd/wordpiece.py, pinned by goldens from HF's tokenizer) on that one string — capital sigma
+ * (context-dependent lower case), invalid UTF-8, list literals using syntax beyond plain quoted
+ * strings, and every non-ASCII string when CLIP_TOK_ASCII_ONLY is set (the caller's Unicode tables
+ * are of another version than clip_tok_unicode_version()).  Results are bit-identical to that
+ * restatement (tests/test_fast_tokenizer.py).
  *
  * Conventions: `int` status (0 = ok, negative = error, message from clip_tok_last_error()); no C++
  * exceptions cross the ABI; strings are UTF-8 bytes in one blob with n+1 offsets (the Arrow
@@ -35,9 +38,10 @@ enum { CLIP_TOK_OK = 0, CLIP_TOK_ERR_ARG = -1, CLIP_TOK_ERR_IO = -2, CLIP_TOK_ER
 /* text modes of clip_tok_encode_plain */
 enum {
   CLIP_TOK_TEXT = 0,      /* the bytes are the text; "[SEP]" etc. written literally map to their ids */
-  CLIP_TOK_LIST_CELL = 1  /* the bytes are a Python list-of-str literal, the `sentence` cell of the
+  CLIP_TOK_LIST_CELL = 1, /* the bytes are a Python list-of-str literal, the `sentence` cell of the
                              reference's CSVs: text = ' '.join(items).lower()  (neural_baselines.py:
                              197-201 + bert.py:100) */
+  CLIP_TOK_ASCII_ONLY = 256 /* OR-ed into the mode: flag every non-ASCII string instead of using the tables */
 };
 
 /* vocab.txt: one token per line, id = line number; must hold [PAD] [UNK] [CLS] [SEP] [MASK]. */
@@ -57,6 +61,8 @@ int clip_tok_encode_plain(clip_tokenizer* t, const char* blob, const int64_t* of
                           int64_t* ids_off, uint8_t* fallback);
 
 const char* clip_tok_last_error(void);
+/* Unicode version of the built-in tables, e.g. "13.0.0" */
+const char* clip_tok_unicode_version(void);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(clip_tok_[a-z0-9_]+)\s*\(", src)))
     lib = FT.load()
-    assert names == sorted(FT.SIGNATURES) and len(names) == 6
+    assert names == sorted(FT.SIGNATURES) and len(names) == 7
     for n in names:
         assert hasattr(lib, n), n
     assert lib.clip_tok_create(None, 1, None) == -1 and b"null" in lib.clip_tok_last_error()
@@ -53,7 +53,7 @@ def test_text_mode_matches_python_tokenizer(fast):
     flat, off, fb = fast.encode_plain_many(texts)
     ref = [fast.py.encode_plain(t) for t in texts]
     assert _rows_of(flat, off) == ref
-    assert [t for t, f in zip(texts, fb) if f] == [t for t in texts if not t.isascii()]   # only those fall back
+    assert [t for t, f in zip(texts, fb) if f] == ["Σίσυφος"]       # capital sigma: context-dependent lower case
     # thread count changes nothing
     one = FT.FastWordPiece(VOCAB, n_threads=1)
     big = texts * 20
@@ -84,8 +84,8 @@ def test_list_cell_mode_matches_python_path(fast):
     handled = dict(zip(cells, ~fb))
     assert handled["['it\\'s', \"say \\\"hi\\\"\", 'back\\\\slash']"] and handled["['a',]"] and handled["[]"]
     assert not handled["[1, 2]"] and not handled["['\\x41']"] and not handled["plain words here"]
-    assert fb[n_csv:].sum() == 15
-    assert [c.isascii() for c in cells[:n_csv]] == list(~fb[:n_csv])       # CSV cells: only non-ASCII ones fall back
+    assert fb[n_csv:].sum() == 14                                          # "['café']" is the library's now
+    assert not fb[:n_csv].any()                                            # every cell of the CSV, non-ASCII ones included
 
 
 def _synthetic_csv(path, n_docs=60, seed=3):
@@ -128,3 +128,81 @@ def test_build_rows_fast_equals_build_rows(fast, tmp_path, n):
             assert (ref.lens >= 500).any()          # the trim branch was exercised
             seps = np.add.reduceat((ref.flat == fast.sep_token_id).astype(np.int64), ref.offsets[:-1])
             assert (seps == 2 * n + 1).all()        # the invariant bert_model.py:52 needs
+
+
+def _fuzz_strings(n, seed):
+    rng = np.random.default_rng(seed)
+    special = [0x130, 0x3C2, 0x3C3, 0x2028, 0x2029, 0x85, 0xA0, 0xAD, 0x200B, 0xFFFD, 0x0, 0xE000, 0x378, 0x1F600,
+               0x10FFFF, 0xFB01, 0x1E9E, 0x1C5, 0x1F88, 0x0344, 0x0F73, 0x1D15E, 0x3000, 0x1680, 0xFF01, 0x2014]
+    ascii_pool = [ord(c) for c in "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789      .,;:!?()[]-'\"/\t\n"]
+    out = []
+    for _ in range(n):
+        cps = []
+        for _ in range(int(rng.integers(0, 40))):
+            r = rng.random()
+            if r < 0.45:
+                cp = int(rng.choice(ascii_pool))
+            elif r < 0.60:
+                cp = int(rng.integers(0xA0, 0x250))            # Latin-1, Latin Extended
+            elif r < 0.68:
+                cp = int(rng.integers(0x300, 0x370))            # combining marks (reordering, stripping)
+            elif r < 0.78:
+                cp = int(rng.integers(0x370, 0x530))            # Greek, Cyrillic, Armenian (capital sigma among them)
+            elif r < 0.81:
+                cp = int(rng.integers(0xAC00, 0xD7A4))          # Hangul syllables
+            elif r < 0.84:
+                cp = int(rng.integers(0x4E00, 0x4F00))          # CJK
+            elif r < 0.90:
+                cp = int(rng.choice(special))
+            else:
+                cp = int(rng.integers(0x80, 0x30000))
+                if 0xD800 <= cp <= 0xDFFF:
+                    cp = 0x263A
+            cps.append(cp)
+        out.append("".join(map(chr, cps)))
+    return out
+
+
+@pytest.mark.parametrize("lower", [True, False])
+def test_unicode_path_matches_python_tokenizer(tmp_path, lower):
+    """Random strings over many scripts, marks, separators and unassigned / private-use code points: the
+    code-point path of the library equals the Python restatement; only capital sigma is handed back."""
+    vocab = open(VOCAB, encoding="utf-8").read().split("\n")
+    vocab = [v for v in vocab if v] + ["é", "##é", "e", "##e", "caf", "ß", "##ß", "α", "##α", "σ", "ς", "##ς", "日", "本", "i", "##̇",
+                                        "ᄀ", "##ᅡ", "##ᆨ", "¿", "ø", "##ø", "д", "##д", "ﬁ", "\u2028x"]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(dict.fromkeys(vocab)) + "\n", encoding="utf-8")
+    f = FT.FastWordPiece(str(vf), do_lower_case=lower, n_threads=4)
+    assert f.mode_flags == 0
+    texts = _fuzz_strings(4000, 7 + lower) + ["café ß Straße", "İstanbul", "ǅ ǆ", "각 한국어", "日本語", "a\u0301\u0323b", "¿qué?",
+                                               "ςσ ΣΑΣ", "x\u2028y\u2029z", "[SEP]é[CLS]", "ﬁn"]
+    flat, off, fb = f.encode_plain_many(texts)
+    ref = [f.py.encode_plain(t) for t in texts]
+    got = _rows_of(flat, off)
+    bad = [i for i in range(len(texts)) if got[i] != ref[i]]
+    assert not bad, (texts[bad[0]].encode("unicode_escape"), got[bad[0]], ref[bad[0]])
+    import unicodedata
+    for t, flagged in zip(texts, fb):      # handed back exactly when a capital sigma reaches the lower-casing step
+        if lower:
+            assert flagged == ("\u03a3" in unicodedata.normalize("NFD", t)), t.encode("unicode_escape")
+        else:
+            assert not flagged
+    # the same strings as list cells (repr() escapes some code points as \x.. / \u....: those are Python's)
+    cells = [str([t[:len(t) // 2], t[len(t) // 2:]]) for t in texts]
+    from clip_amd.datasets import _parse_list
+    text = lambda i: " ".join(str(x) for x in _parse_list(cells[i], lower=False)).lower()
+    flat, off, fb = f.encode_plain_many(cells, FT.MODE_LIST_CELL, py_text=text)
+    assert _rows_of(flat, off) == [f.py.encode_plain(text(i)) for i in range(len(cells))]
+    assert (~fb).sum() > len(cells) // 4
+
+
+def test_ascii_only_flag_hands_back_every_non_ascii_string(fast):
+    saved = fast.mode_flags
+    try:
+        fast.mode_flags = FT.MODE_ASCII_ONLY
+        texts = ["plain", "café", "x" * 10, "日本"]
+        flat, off, fb = fast.encode_plain_many(texts)
+        assert list(fb) == [False, True, False, True]
+        assert _rows_of(flat, off) == [fast.py.encode_plain(t) for t in texts]
+    finally:
+        fast.mode_flags = saved
