@@ -20,11 +20,8 @@ running top-k; CSV parts are concatenated in chunk order (= input order) and the
 all-gather.
 """
 import argparse
-import csv
 import os
-import sys
 
-import numpy as np
 import torch
 
 from . import topk as topk_mod

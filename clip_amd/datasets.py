@@ -7,7 +7,6 @@ said where it applies.
 """
 import ast
 
-import numpy as np
 import pandas as pd
 
 
