@@ -179,6 +179,12 @@ def main():
                 traffic = pmc["kernels"]["gemm8_kernel<1, false, false>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        mfma_busy = None      # MFMA busy cycles / kernel cycles of the dominant kernel, from an SQ PMC pass kept under profiles/
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v10_pmc_mfma_util.json")) as fh:
+                mfma_busy = json.load(fh)["gemm8_kernel<1, false, false>"]["mfma_utilisation"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "sentences/sec scored (whole node) BERT-base+Context seq256 bf16",
             "value": round(value, 2), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
@@ -195,6 +201,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "mfma_busy_frac_pmc": mfma_busy,
                          "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/%s); algorithmic operand+output bytes = %d" % (PMC_FILE, 2 * T * H + 2 * I * H + 2 * T * I),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
