@@ -96,11 +96,14 @@ def balance_each_label(yhat_raw, y):
     return metrics, threshs, rec_values
 
 
-def _macro_micro(pred, y):
-    """ref: multilabel_eval.py:209-260 (all_macro / all_micro) for pred, y bool [N, L]."""
+def _macro_micro(pred, y, f32_pred=False):
+    """ref: multilabel_eval.py:209-260 (all_macro / all_micro) for pred, y bool [N, L].
+    f32_pred: the caller's predictions were a float32 array (np.round of float32 scores, bert.py:225):
+    `yhat.sum(axis=0) + 1e-10` is then a float32 sum, which swallows the 1e-10 unless the sum is 0."""
     inter = (pred & y).sum(0).astype(np.float64)
     union = (pred | y).sum(0).astype(np.float64)
-    mp = float(np.mean(inter / (pred.sum(0) + 1e-10)))
+    pden = (pred.sum(0).astype(np.float32) + np.float32(1e-10)).astype(np.float64) if f32_pred else pred.sum(0) + 1e-10
+    mp = float(np.mean(inter / pden))
     mr = float(np.mean(inter / (y.sum(0) + 1e-10)))
     macro = (float(np.mean(inter / (union + 1e-10))), mp, mr, 0. if mp + mr == 0 else 2 * mp * mr / (mp + mr))
     ti, tu = float(inter.sum()), float(union.sum())
@@ -173,3 +176,87 @@ def fit_label_thresholds(scorer, rows, labels, out_path=None):
     if out_path is not None:
         np.save(out_path, threshs)
     return threshs, metrics
+
+
+# ------------------------------------------------------------------ the rest of bert.py:284-315
+def roc_auc_curve(y, scores):
+    """sklearn.metrics.auc(*roc_curve(y, scores)[:2]): trapezoid area over the ROC points at the
+    distinct score values (no collinear-point dropping needed for the area).  nan when y has no
+    positive or no negative (sklearn warns and returns nan there)."""
+    y = np.asarray(y).astype(bool)
+    s = np.asarray(scores).astype(np.float64)
+    n_pos, n_neg = int(y.sum()), int((~y).sum())
+    if n_pos == 0 or n_neg == 0:
+        return float("nan")
+    order = np.argsort(-s, kind="stable")
+    ys, ss = y[order], s[order]
+    last = np.flatnonzero(np.concatenate((ss[1:] != ss[:-1], [True])))      # last index of each distinct score
+    tps = np.concatenate(([0], np.cumsum(ys)[last]))
+    fps = np.concatenate(([0], np.cumsum(~ys)[last]))
+    return float(np.trapezoid(tps / n_pos, fps / n_neg))
+
+
+def all_metrics(yhat, y, yhat_raw=None, calc_auc=True, label_order=LABEL_TYPES):
+    """ref: multilabel_eval.py:18-52 (+ auc_metrics :262-292): per-label F1 at the 0.5 rounding,
+    macro / micro accuracy, precision, recall, F1, macro / micro AUC."""
+    f32_pred = np.asarray(yhat).dtype == np.float32
+    yhat, yb = np.asarray(yhat).astype(bool), np.asarray(y).astype(bool)
+    metrics = {}
+    for ix, label in enumerate(label_order):
+        tp, fp, fn, _ = _confusion(yhat[:, ix], yb[:, ix])
+        metrics[f"{label2abbrev[label]}-f1"] = float(_safe_div(2 * tp, 2 * tp + fp + fn))
+    macro, micro = _macro_micro(yhat, yb, f32_pred)
+    for n, v in zip(("acc", "prec", "rec", "f1"), macro):
+        metrics[f"{n}_macro"] = v
+    for n, v in zip(("acc", "prec", "rec", "f1"), micro):
+        metrics[f"{n}_micro"] = v
+    if yhat_raw is not None and calc_auc and len(yb) > 1:
+        raw = np.asarray(yhat_raw)
+        aucs = []
+        for i in range(yb.shape[1]):
+            if yb[:, i].sum() > 0:                        # only labels with true positives (:273)
+                a = roc_auc_curve(yb[:, i], raw[:, i])
+                if not np.isnan(a):
+                    aucs.append(a)
+        metrics["auc_macro"] = float(np.mean(aucs)) if aucs else float("nan")
+        metrics["auc_micro"] = roc_auc_curve(yb.ravel(), raw.ravel())
+    return metrics
+
+
+def precision_at_fixed_recall(scores, y, fixed_metric):
+    """ref: binary_eval.py:34-42 — threshold that keeps `fixed_metric` of the true positives, and the
+    precision there (`>=`)."""
+    s = np.asarray(scores)
+    yb = np.asarray(y).astype(bool)
+    tmp = s * yb
+    true_scores = np.sort(tmp[tmp > 0])
+    thresh = true_scores[round(len(true_scores) * (1 - fixed_metric)) - 1]
+    pred = s >= thresh
+    tp, fp, _, _ = _confusion(pred, yb)
+    return thresh, float(_safe_div(tp, tp + fp))
+
+
+def evaluate_scores(yhat_raw, y):
+    """The multilabel branch of the reference's `evaluate` (bert.py:284-315) on scores already gathered:
+    unbalanced metrics at 0.5, per-label balanced thresholds, the micro-F1 threshold, the binary
+    (any-label) view at the per-label thresholds, precision at 90 / 95 / 99 % recall of the binary view.
+    Returns (metrics, label_threshs, micro_thresh, rec_90_thresh, rec_95_thresh, rec_99_thresh)."""
+    yhat_raw, y = np.asarray(yhat_raw), np.asarray(y)
+    metrics = all_metrics(np.round(yhat_raw), y, yhat_raw=yhat_raw)
+    label_metrics, label_threshs, _ = balance_each_label(yhat_raw, y)
+    metrics.update(label_metrics)
+    micro_thresh, micro_metrics = balanced_f1_micro(yhat_raw, y)
+    metrics.update({f"balanced_{k}": v for k, v in micro_metrics.items()})
+    binary_yhat = np.any(yhat_raw >= np.asarray(label_threshs), axis=1)          # :300, `>=` as written
+    binary_y = np.any(y, axis=1)
+    tp, fp, fn, _ = _confusion(binary_yhat, binary_y)
+    metrics["binary_prec"] = float(_safe_div(tp, tp + fp))
+    metrics["binary_rec"] = float(_safe_div(tp, tp + fn))
+    metrics["binary_f1"] = float(_safe_div(2 * tp, 2 * tp + fp + fn))
+    binary_raw = np.max(yhat_raw, axis=1)
+    out = []
+    for r in (0.90, 0.95, 0.99):
+        t, p = precision_at_fixed_recall(binary_raw, binary_y, r)
+        metrics[f"prec@rec={int(round(r * 100))}"] = p
+        out.append(float(t))
+    return (metrics, label_threshs, micro_thresh) + tuple(out)

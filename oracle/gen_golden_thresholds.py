@@ -50,6 +50,19 @@ def main():
             metrics, threshs, _, _, rec_values = ME.balance_each_label(p, y)
             micro_t, micro_m = ME.balanced_f1(p, y)
             given = ME.macro_metrics_given_thresholds(p, y, threshs)
+            allm = ME.all_metrics(np.round(p), y, yhat_raw=p, calc_auc=True, label_order=ME.LABEL_TYPES)
+            import binary_eval as BE
+            from sklearn.metrics import precision_score, recall_score, f1_score
+            binary_yhat = np.any(p >= np.array(threshs), axis=1)          # bert.py:300-304
+            binary_y = np.any(y, axis=1)
+            binary = {"binary_prec": precision_score(binary_y, binary_yhat), "binary_rec": recall_score(binary_y, binary_yhat),
+                      "binary_f1": f1_score(binary_y, binary_yhat)}
+            braw = np.max(p, axis=1)
+            braw2 = np.stack((1 - braw, braw), axis=1)                    # bert.py:308-315
+            fixed = {}
+            for r in (0.90, 0.95, 0.99):
+                t, pr = BE.precision_at_fixed_recall(braw2, binary_y, r)
+                fixed[str(int(round(r * 100)))] = [float(t), float(pr)]
         out[name] = {
             "gen": kw,
             "label_threshs": [float(t) for t in threshs],
@@ -57,6 +70,8 @@ def main():
             "rec_values": {k: [float(x) for x in v] for k, v in rec_values.items()},
             "micro_thresh": float(micro_t), "micro_metrics": {k: float(v) for k, v in micro_m.items()},
             "given_thresholds": {k: float(v) for k, v in given.items()},
+            "all_metrics": {k: float(v) for k, v in allm.items()},
+            "binary": {k: float(v) for k, v in binary.items()}, "prec_at_fixed_recall": fixed,
             "checksum_scores": float(p.astype(np.float64).sum()), "checksum_y": int(y.sum()),
         }
         print(name, "thresholds", out[name]["label_threshs"], "micro", micro_t)

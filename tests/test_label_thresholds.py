@@ -54,6 +54,21 @@ def test_threshold_search_matches_reference(case):
         assert given[k] == pytest.approx(v, abs=1e-12), k
 
 
+@pytest.mark.parametrize("case", sorted(GOLD))
+def test_evaluate_scores_matches_reference(case):
+    """The multilabel branch of bert.py `evaluate` (:284-315): all_metrics + AUCs, the binary (any-label)
+    view at the per-label thresholds, precision at fixed recall."""
+    g = GOLD[case]
+    p, y = _gen().synth_scores(**g["gen"])
+    metrics, label_threshs, micro_thresh, t90, t95, t99 = LT.evaluate_scores(p, y)
+    assert label_threshs == g["label_threshs"] and micro_thresh == g["micro_thresh"]
+    for k, v in {**g["all_metrics"], **g["binary"]}.items():
+        assert (np.isnan(v) and np.isnan(metrics[k])) or metrics[k] == pytest.approx(v, abs=1e-13), k
+    for r, t in (("90", t90), ("95", t95), ("99", t99)):
+        assert t == g["prec_at_fixed_recall"][r][0]
+        assert metrics[f"prec@rec={r}"] == pytest.approx(g["prec_at_fixed_recall"][r][1], abs=1e-13)
+
+
 def test_roc_auc_ties_and_single_class():
     y = np.array([0, 0, 1, 1])
     assert LT.roc_auc(y, np.array([0.1, 0.4, 0.35, 0.8])) == pytest.approx(0.75)
