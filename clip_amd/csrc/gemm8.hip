@@ -27,6 +27,8 @@
 //  * Epilogue as in gemm_persist.hip (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
 //    transpose, whole 128-byte row segments, non-temporal stores left in flight), through a 2-KiB
 //    scratch per wave beside the ring; the bias slice travels by LDS-DMA one tile ahead.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -561,6 +563,10 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     n_cu = cus & ~7;
     if (n_cu < 8) return hipErrorInvalidValue;
+    if (const char* cap = getenv("GEMM8_MAX_WGS")) {   // diagnostic: tools/dual_stream_bench.py
+      const int c = atoi(cap) & ~7;
+      if (c >= 8 && c < n_cu) n_cu = c;
+    }
   }
   const int tiles_m = g.M / BM, tiles_n = g.N / BN, n_tiles = tiles_m * tiles_n;
   const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
