@@ -98,3 +98,23 @@ def test_bulk_scorer_flags_wrong_sep_count(golden):
     rows = [np.array([101, 5, 102, 6, 102, 7, 102], np.int32)]
     with pytest.raises(TypeError):
         scoring.BulkScorer(model).score(rows)
+
+
+def test_bulk_scorer_edge_inputs(golden):
+    """No rows at all, one row, a row longer than the position table, a row larger than a step."""
+    g = golden("tiny_ctx")
+    model = _model(g["cfg"], g["seed"], 2, max_tokens=2048, max_seqs=64)
+    sc = scoring.BulkScorer(model, keep_probs=True)
+    res = sc.score([])
+    assert len(res.max_score) == 0 and res.probs.shape == (0, 7) and res.keep.dtype == bool
+    one = sc.score(g["rows"][:1])
+    many = sc.score(g["rows"][:9])
+    assert np.array_equal(one.probs[0], many.probs[0])                 # a row's result does not depend on its batch
+    too_long = np.concatenate(([101], np.full(600, 1500), [102, 102, 102, 102, 102])).astype(np.int32)
+    with pytest.raises(_lib.ClipError):
+        sc.score([too_long])                                           # 606 tokens > max_position_embeddings
+    small = scoring.BulkScorer(model, tokens_per_step=64)
+    with pytest.raises(ValueError):
+        small.score([g["rows"][-1]])                                   # a 512-token row cannot fit a 64-token step
+    with pytest.raises(ValueError):
+        scoring.BulkScorer(model, tokens_per_step=4096)                # beyond the engine's workspace
