@@ -39,9 +39,10 @@ def flops_per_row(L, cfg):
 
 
 def flops_saved_per_row(L, cfg):
-    """Last-layer trimming: past the K/V projection only the pooled row is computed."""
+    """Last-layer trimming: only the pooled row's q, attention, output projection and FFN
+    are computed there; K and V still need every token."""
     H, I = cfg.hidden_size, cfg.intermediate_size
-    return 2 * (L - 1) * (H * H + 2 * H * I) + 4 * L * H * (L - 1)
+    return 2 * (L - 1) * (2 * H * H + 2 * H * I) + 4 * L * H * (L - 1)
 
 
 def make_batch(rows, device):

@@ -202,11 +202,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 // (ref: sentclf/bert_model.py:52-58 gathers ONE hidden row per sentence; :234 uses row 0), so its
 // attention output is the only one needed: one wave per (sequence, head), q row against all keys.
 // HBM-bound (reads every K and V row once); softmax weights stay fp32.
+// q_rows (optional): the focus tokens' q projections as a dense [n_seqs, hidden] tensor — the last layer
+// then projects q for those rows only, and its all-token GEMM stops at K and V.
 __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __restrict__ qkv,
                                                              const int32_t* __restrict__ cu,
                                                              const int32_t* __restrict__ focus,
                                                              bf16_t* __restrict__ ctx_rows,
-                                                             int hidden) {
+                                                             int hidden, const bf16_t* __restrict__ q_rows) {
   __shared__ float q_s[HD];
   __shared__ float p_s[512];
   const int seq = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   const int ld = 3 * hidden;
   const bf16_t* kbase = qkv + (size_t)beg * ld + hidden + head * HD;
   const bf16_t* vbase = kbase + hidden;
-  q_s[lane] = bf16_to_f32(qkv[(size_t)focus[seq] * ld + head * HD + lane]);
+  q_s[lane] = bf16_to_f32(q_rows ? q_rows[(size_t)seq * hidden + head * HD + lane]
+                                 : qkv[(size_t)focus[seq] * ld + head * HD + lane]);
   __syncthreads();
   float sc[8];
   float mx = -INFINITY;
@@ -365,11 +368,11 @@ hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, flo
 
 hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
                                   const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
-                                  int hidden, hipStream_t st) {
+                                  int hidden, hipStream_t st, const bf16_t* q_rows) {
   if (n_seqs <= 0) return hipSuccess;
   if (hidden != n_heads * HD) return hipErrorInvalidValue;
   hipLaunchKernelGGL(attention_focus_kernel, dim3(n_seqs, n_heads), dim3(64), 0, st, qkv, cu_seqlens,
-                     focus, ctx_rows, hidden);
+                     focus, ctx_rows, hidden, q_rows);
   return hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ struct clip_engine {
   bool f32 = false;
   // workspace (allocated by clip_finalize_weights, element size by precision)
   void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
-       *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr;
+       *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr, *xf_rows = nullptr, *q_rows = nullptr;
   // fp32 pre-LayerNorm rows and their (mean, rstd), double-buffered: a GEMM writes pre[b ^ 1] while
   // its epilogue re-derives the residual from pre[b] / stats[b] (EPI_BIAS_LNRES)
   float *pre[2] = {nullptr, nullptr}, *stats[2] = {nullptr, nullptr};
@@ -141,6 +141,8 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, &e->rows, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->pooled, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->ctx_rows, S * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->xf_rows, S * H * es);
+  rc = rc ? rc : dev_alloc(e, &e->q_rows, S * H * es);
   rc = rc ? rc : dev_alloc(e, &e->mid_rows, S * I * es);
   for (int b = 0; b < 2; ++b) rc = rc ? rc : dev_alloc(e, (void**)&e->stats_rows[b], S * 8);
   const size_t n_tiles = (Tp / 256) * ((H + 255) / 256);
@@ -423,12 +425,25 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   const bool trim = e->trim_last && max_seqlen <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
+    if (trim && i == c.num_layers - 1) {
+      // The rest of the last layer runs on n_seqs rows: only the pooled token's q is ever read, so the
+      // all-token GEMM stops at K and V (the k|v rows of the fused weight, the k|v columns of qkv) and q
+      // is projected for the gathered focus rows alone (same bits: a row's result does not depend on the
+      // GEMM kernel that computes it).
+      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
+      g = GemmArgs{e->x, static_cast<bf16_t*>(L.wqkv) + (size_t)H * H, L.bqkv + H, nullptr,
+                   static_cast<bf16_t*>(e->qkv) + H, Tg, 2 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      HIP_TRY(launch_gemm(g, st));
+      HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
+      g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
+      HIP_TRY(launch_gemm(g, st));
+      break;
+    }
     {
       ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
       g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, f32, 0, f32};
       HIP_TRY(launch_gemm(g, st));
     }
-    if (trim && i == c.num_layers - 1) break;  // the rest of the last layer runs on n_seqs rows
     {
       ProfScope ps(e, CLIP_KIND_ATTENTION, st);
       if (f32)
@@ -483,7 +498,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
       HIP_TRY(launch_attention_focus(static_cast<const bf16_t*>(e->qkv), cu, focus,
-                                     static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st));
+                                     static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st,
+                                     static_cast<const bf16_t*>(e->q_rows)));
     }
     {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass

@@ -65,7 +65,8 @@ hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, flo
 // one q row per sequence (token index focus[s]): ctx_rows [n_seqs, H] bf16; sequences up to 512 keys
 hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
                                   const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
-                                  int hidden, hipStream_t st);
+                                  int hidden, hipStream_t st,
+                                  const bf16_t* q_rows = nullptr);  // optional dense [n_seqs, hidden] q of the focus tokens
 // out_bf16[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]])
 hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
                            const float* word, const float* pos, const float* type,
