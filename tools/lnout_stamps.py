@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65280
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 N = 768
-lib = C.CDLL(os.path.join(ROOT, "gpurun_tmp", "libstamps.so"))
+lib = C.CDLL(os.path.join(ROOT, "gpurun_tmp", os.environ.get("STAMPS_LIB", "libstamps.so")))
 lib.clip_gemm_bf16_lnout.argtypes = _lib.SIGNATURES["clip_gemm_bf16_lnout"]
 lib.clip_gemm_bf16_lnout.restype = C.c_int
 g = torch.Generator(device="cpu").manual_seed(0)
