@@ -71,21 +71,13 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # backend "nccl" IS RCCL on ROCm.  CLIP_DIST_BACKEND=gloo is for rehearsing the multi-rank code
-        # path on a box with fewer GPUs than ranks (ranks then share a card: functional check only)
-        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    # --gpus N without torchrun: this process starts the N ranks itself (fresh processes, before any
+    # GPU call here) and only relays their exit status; rank 0 of the children prints the JSON line
+    from clip_amd import launch
+    rc = launch.spawn_ranks_if_needed(args.gpus)
+    if rc is not None:
+        sys.exit(rc)
+    dist, rank, world, device = launch.init_distributed()
 
     cfg = BertConfig()
     n_ctx = 2
@@ -145,6 +137,12 @@ def main():
     cnt = (C.c_int64 * len(_lib.KINDS))()
     _lib.check(lib.clip_profile_read(engine, ms, cnt, 1))
     _lib.check(lib.clip_profile_enable(engine, 0))
+    # device-side error words after the timed loop, on every rank: a non-zero word voids the run
+    flags = C.c_int32(0)
+    _lib.check(lib.clip_poll_errors(engine, C.byref(flags)))
+    if flags.value or int(err.item()):
+        raise RuntimeError(f"rank {rank}: engine error word {flags.value}, [SEP]-count word {int(err.item())} "
+                           "after the timed loop: results void")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +205,10 @@ def main():
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),
                          "flops_per_launch": gemm_flops},
         }
+        res["dist"] = {"world_size": dist.get_world_size() if dist is not None else 1,
+                       "backend": dist.get_backend() if dist is not None else None,
+                       "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else None),
+                       "gpus_visible": torch.cuda.device_count()}
         res["topk"] = {"k": 64, "records": int(len(glob)), "ms_local_select_allgather_merge": round(topk_ms, 3)}
         if args.breakdown:
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}

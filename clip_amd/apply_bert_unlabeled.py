@@ -24,7 +24,7 @@ import os
 
 import torch
 
-from . import topk as topk_mod
+from . import launch, topk as topk_mod
 from .bert_model import args_to_model
 from .fast_tokenizer import FastWordPiece, build_rows_fast
 from .config import BertConfig
@@ -52,54 +52,62 @@ def main(argv=None):
                         help="rows scored per chunk of whole documents (bounds host memory; chunk c -> rank c mod world)")
     parser.add_argument("--save_rows", type=str, default=None,
                         help="write the tokenised rows as a columnar directory (tokenise once, score many times)")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="ranks to start, one per MI355X (documents are sharded; ignored under torchrun)")
     parser.add_argument("--tokenize_only", action="store_true", help="stop after --save_rows (needs no GPU)")
     args = parser.parse_args(argv)
     if args.task != "multilabel":
         raise NotImplementedError("only --task multilabel is on the accelerated path")
 
+    # --gpus N: this process starts the N ranks itself (clip_amd/launch.py); under torchrun they exist already
+    rc = launch.spawn_ranks_if_needed(args.gpus, module="clip_amd.apply_bert_unlabeled") if argv is None else None
+    if rc is not None:
+        raise SystemExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = device = None
+    if not args.tokenize_only:
+        dist, rank, world, device = launch.init_distributed()
 
-    # ---- rows: a columnar directory as it is, or the CSV through the C++ front end
+    # ---- rows: a columnar directory as it is, or the CSV through the C++ front end — ONCE per job:
+    # rank 0 tokenises on all host cores and writes the columnar directory, every rank memory-maps it
+    # (N ranks tokenising the same CSV would be N x the work on the same cores)
+    out_dir = os.path.dirname(args.local_weights) or "."                               # :90
     if os.path.isdir(args.unlabeled_fname):
-        corpus = ColumnarCorpus(args.unlabeled_fname)
-        if corpus.meta.get("n_context_sentences") != args.n_context_sentences:
-            raise ValueError(f"{args.unlabeled_fname} was tokenised with n_context_sentences="
-                             f"{corpus.meta.get('n_context_sentences')}, not {args.n_context_sentences}")
-        sep_id = int(corpus.meta["sep_token_id"])
+        corpus_dir = args.unlabeled_fname
+        corpus = None
     else:
-        # C++ WordPiece on all host cores (libclip_tok.so); the Python restatement behind it takes what it flags
-        tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                # :43-47
-        if args.n_context_sentences == 0:                                              # :83-88
-            dataset = SentDataset(args.unlabeled_fname, args.task)
-        else:
-            dataset = SentEvalDataset(args.unlabeled_fname, args.task,
-                                      n_context_sentences=args.n_context_sentences)
-        rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
-        sep_id = tokenizer.sep_token_id
-        meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=sep_id,
-                    cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
-                    source=os.path.basename(args.unlabeled_fname))
-        corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
-        if args.save_rows and rank == 0:
-            save_rows(args.save_rows, rows, doc_ids, sent_ixs, **meta)
+        corpus_dir = args.save_rows or (os.path.join(out_dir, "ttp_rows.columnar") if world > 1 else None)
+        corpus = None
+        if rank == 0:
+            # C++ WordPiece (libclip_tok.so); the Python restatement behind it takes what it flags
+            tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                # :43-47
+            if args.n_context_sentences == 0:                                              # :83-88
+                dataset = SentDataset(args.unlabeled_fname, args.task)
+            else:
+                dataset = SentEvalDataset(args.unlabeled_fname, args.task,
+                                          n_context_sentences=args.n_context_sentences)
+            rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
+            meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=tokenizer.sep_token_id,
+                        cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
+                        source=os.path.basename(args.unlabeled_fname))
+            if corpus_dir:
+                save_rows(corpus_dir, rows, doc_ids, sent_ixs, **meta)
+            if world == 1:
+                corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
+        if dist is not None:
+            dist.barrier()
+    if corpus is None:
+        corpus = ColumnarCorpus(corpus_dir)
+        if corpus.meta.get("n_context_sentences") != args.n_context_sentences:
+            raise ValueError(f"{corpus_dir} was tokenised with n_context_sentences="
+                             f"{corpus.meta.get('n_context_sentences')}, not {args.n_context_sentences}")
+    sep_id = int(corpus.meta["sep_token_id"])
     if args.tokenize_only:
         if not args.save_rows:
             raise ValueError("--tokenize_only needs --save_rows")
         print(f"tokenised {len(corpus)} rows / {corpus.meta['tokens']} tokens -> {args.save_rows}")
         return None
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")     # "gloo": rehearsal on fewer GPUs than ranks
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
 
     config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
     model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,
@@ -119,7 +127,6 @@ def main(argv=None):
     # ---- the hot loop (:92-124), chunk by chunk: score, append this chunk's CSV part, fold into the
     # running top-k.  Chunks are whole documents; chunk c belongs to rank c mod world.
     scorer = BulkScorer(model, any_threshold=args.threshold)
-    out_dir = os.path.dirname(args.local_weights) or "."                               # :90
     out = os.path.join(out_dir, "ttp_doc_sents.csv")
     n_chunks = len(corpus.chunk_bounds(args.chunk_rows))
     top = RunningTopK(args.topk) if args.topk > 0 else None
@@ -144,8 +151,12 @@ def main(argv=None):
         glob = topk_mod.global_topk(top.records, args.topk)
         if rank == 0:
             write_topk_csv(os.path.join(out_dir, f"ttp_top{args.topk}.csv"), glob)
+    tot = torch.tensor([n_kept, n_rows], dtype=torch.int64,
+                       device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(tot)                            # counts over all ranks
     if rank == 0:
-        print(f"done! results in {out_dir}  ({n_kept} of {n_rows} sentences selected on rank 0)")
+        print(f"done! results in {out_dir}  ({int(tot[0])} of {int(tot[1])} sentences selected, {world} rank(s))")
     if dist is not None:
         dist.destroy_process_group()
     return res

@@ -1,6 +1,6 @@
 """Full-size synthetic scoring jobs (BASELINE.json configs C2 / C4 / C5) end to end on one node:
 
-    python -m clip_amd.job --config C4 --rows 10000000 --topk 250000
+    python -m clip_amd.job --config C4 --rows 10000000 --topk 250000 [--gpus 8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m clip_amd.job --config C5 --rows 50000000 --topk 250000 --out ttp_top250000.csv
 
@@ -96,22 +96,16 @@ def main(argv=None):
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--tokens-per-step", type=int, default=131072)
     ap.add_argument("--weights", type=str, default=None, help="state dict (.safetensors); default: procedural")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start, one per MI355X (ignored under torchrun)")
     ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
     args = ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CLIP_DIST_BACKEND", "nccl")     # "gloo": rehearsal on fewer GPUs than ranks
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    # --gpus N: this process starts the N ranks itself (clip_amd/launch.py); under torchrun they exist already
+    from . import launch
+    rc = launch.spawn_ranks_if_needed(args.gpus, module="clip_amd.job") if argv is None else None
+    if rc is not None:
+        raise SystemExit(rc)
+    dist, rank, world, device = launch.init_distributed()
 
     cfg = BertConfig()
     n_ctx = CONFIGS[args.config][0]
@@ -153,6 +147,7 @@ def main(argv=None):
             write_topk_csv(args.out, glob)
         print(json.dumps({
             "job": args.config, "rows": int(tot[0]), "tokens": int(tot[1]), "kept": int(tot[2]), "n_gpus": world,
+            "backend": dist.get_backend() if dist is not None else None,
             "seconds": round(t_all, 3), "rank0_scoring_seconds": round(t_score, 3),
             "sentences_per_s": round(int(tot[0]) / t_all, 1), "tokens_per_s": round(int(tot[1]) / t_all, 1),
             "topk": int(len(glob)), "topk_first": [int(glob[0]["doc_id"]), int(glob[0]["sent_ix"]), float(glob[0]["score"])]

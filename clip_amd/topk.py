@@ -57,17 +57,16 @@ def global_topk(local_records, k, group=None, device=None):
     backend = dist.get_backend(group)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
                                              if backend == "nccl" else torch.device("cpu"))
-    buf = np.zeros(k, RECORD)
+    # ONE collective: k records + one trailer record whose doc_id field carries this rank's count
+    buf = np.zeros(k + 1, RECORD)
     n = min(len(local_records), k)
     buf[:n] = local_records[:n]
-    payload = torch.from_numpy(buf.view(np.uint8).reshape(k, RECORD.itemsize).copy()).to(dev)
-    count = torch.tensor([n], dtype=torch.int64, device=dev)
-    payloads = torch.empty((world * k, RECORD.itemsize), dtype=torch.uint8, device=dev)
-    counts = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(payloads, payload, group=group)       # the one data collective
-    dist.all_gather_into_tensor(counts, count, group=group)           # 8 bytes per rank
-    payloads, counts = payloads.cpu().numpy().reshape(world, k, RECORD.itemsize), counts.cpu().numpy()
-    parts = [payloads[r, :counts[r]].copy().reshape(-1).view(RECORD) for r in range(world)]
+    buf[k]["doc_id"] = n
+    payload = torch.from_numpy(buf.view(np.uint8).reshape(k + 1, RECORD.itemsize).copy()).to(dev)
+    payloads = torch.empty((world * (k + 1), RECORD.itemsize), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(payloads, payload, group=group)
+    recs = payloads.cpu().numpy().reshape(-1).view(RECORD).reshape(world, k + 1)
+    parts = [recs[r, :int(recs[r, k]["doc_id"])].copy() for r in range(world)]
     return merge_topk(parts, k)
 
 
