@@ -79,6 +79,23 @@ def load():
     return lib
 
 
+ERR_LN_TIMEOUT, ERR_ROW_TABLE = 2, 4     # bits of the device error word (clip_poll_errors)
+
+
+def poll_errors(engine):
+    """Read-and-clear the engine's device error word behind its latest forward; raises if non-zero."""
+    flags = C.c_int32(0)
+    check(load().clip_poll_errors(engine, C.byref(flags)))
+    if flags.value & ERR_LN_TIMEOUT:
+        raise RuntimeError(f"engine error word {flags.value}: a fused-LayerNorm exchange timed out (GPU shared "
+                           "with other work? set CLIP_AMD_FUSED_LN=0 there); results of the call are void")
+    if flags.value & ERR_ROW_TABLE:
+        raise ValueError(f"engine error word {flags.value}: inconsistent row table (a row longer than max_seqlen, "
+                         "an empty row, or cu_seqlens not ending at total_tokens); results of the call are void")
+    if flags.value:
+        raise RuntimeError(f"engine error word {flags.value}")
+
+
 def check(rc):
     if rc != CLIP_OK:
         raise ClipError(rc, load().clip_last_error().decode())

@@ -202,6 +202,8 @@ class _EngineModel:
             _lib.check(lib.clip_forward_packed(h, _lib.ptr(ids), _lib.ptr(type_ids), _lib.ptr(pos_ids),
                                                _lib.ptr(cu_seqlens), _lib.ptr(focus), n, T, int(max_seqlen),
                                                self.head_kind, _lib.ptr(logits), _lib.stream_ptr()))
+            if check:      # 4-byte read behind the forward; the bulk loop (clip_amd.scoring) polls once per chunk
+                _lib.poll_errors(h)
         return logits
 
     def _focus(self, ids, cu_seqlens, n_ctx, sep_id, check):

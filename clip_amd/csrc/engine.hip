@@ -1,6 +1,7 @@
 // C ABI of libclip_amd.so (include/clip_amd.h): engine object = device weights + activation
 // workspace; clip_forward_packed chains the kernels of one BERT(+Context) forward on one stream.
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -79,6 +80,8 @@ struct clip_engine {
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
   uint32_t epoch = 0;
+  hipStream_t last_stream = nullptr;  // stream of the latest forward: clip_poll_errors reads behind it
+  bool test_drop = false;             // CLIP_AMD_TEST_DROP_PUBLISH=1 (tests): one fused-LayerNorm tile never publishes
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -229,6 +232,7 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   clip_engine* e = new clip_engine();
   e->cfg = *c;
   e->device = device_id;
+  if (const char* t = getenv("CLIP_AMD_TEST_DROP_PUBLISH")) e->test_drop = t[0] == '1';
   *out = e;
   return CLIP_OK;
 }
@@ -382,8 +386,11 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   if (head_kind != 0 && head_kind != 1) return fail(CLIP_ERR_ARG, "clip_forward_packed: head_kind");
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
+  e->last_stream = st;
   const clip_config& c = e->cfg;
   const int H = c.hidden_size, I = c.intermediate_size;
+  // the row table is the caller's: a row beyond max_seqlen or a table that does not end at T sets bit 2
+  HIP_TRY(launch_check_rows(cu, n_seqs, T, max_seqlen, e->dev_err, st));
 
   const bool f32 = e->f32;
   // Residual operands.  bf16 setting: the GEMM epilogue re-derives the fp32 LayerNorm output from the
@@ -400,7 +407,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
                      const float* beta) {
     GemmArgs a{A, W, bias, first_res ? e->xres_rm : e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta;
-    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err};
+    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err,
+                        e->test_drop ? 1u : 0u};
     first_res = false;
     return launch_gemm(a, st);
   };
@@ -422,7 +430,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
   const int Tg = f32 ? T : (T + 255) / 256 * 256;
   // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
-  const bool trim = e->trim_last && max_seqlen <= 512 && !f32;
+  // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
+  const bool trim = e->trim_last && c.max_position <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
     if (trim && i == c.num_layers - 1) {
@@ -555,6 +564,8 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
                               c.num_labels, st, f32));
   }
+  // a void call (device error word set) must not look like scores: NaN logits, poll or no poll
+  HIP_TRY(launch_poison_logits(e->dev_err, logits, n_seqs * c.num_labels, st));
   return CLIP_OK;
 }
 
@@ -584,8 +595,14 @@ int clip_poll_errors(clip_engine* e, int32_t* host_flags) {
   *host_flags = 0;
   if (!e->dev_err) return CLIP_OK;
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpy(host_flags, e->dev_err, 4, hipMemcpyDeviceToHost));  // synchronises with the engine's work
-  if (*host_flags) HIP_TRY(hipMemset(e->dev_err, 0, 4));
+  // behind the engine's latest forward, on ITS stream (a blocking copy on the null stream does not order
+  // against a non-blocking stream)
+  HIP_TRY(hipMemcpyAsync(host_flags, e->dev_err, 4, hipMemcpyDeviceToHost, e->last_stream));
+  HIP_TRY(hipStreamSynchronize(e->last_stream));
+  if (*host_flags) {
+    HIP_TRY(hipMemsetAsync(e->dev_err, 0, 4, e->last_stream));
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
+  }
   return CLIP_OK;
 }
 

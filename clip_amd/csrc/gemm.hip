@@ -274,13 +274,12 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN, F32IN>;
-  static bool attr_set = false;  // per instantiation; one process drives one GPU
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DeviceOnce once;  // per instantiation and device
+  int unused = 0;
+  hipError_t e0 = once.get([&](int, int*) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  }, &unused);
+  if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(kfn, dim3(tiles_m * tiles_n), dim3(64 * WAVES_M * WAVES_N), LDS, st, g.A, g.W,
                      g.bias, g.res, g.out, g.M, g.N, g.K, g.lda, g.ldw, g.ldo, g.ldres, tiles_m,
                      tiles_n, reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma, g.ln_beta,
@@ -299,6 +298,10 @@ hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+bool gemm_persist_ok(const GemmArgs& g) {  // shapes the ping-pong persistent kernel (gemm8.hip) takes
+  return !g.f32_in && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.M > 0 && g.N > 0 && g.K > 0;
+}
+
 const char* gemm_check(const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: empty problem";
   if (g.K % (g.f32_in ? 32 : 64)) return "gemm: K must be a multiple of 64 (32 in fp32 mode)";
@@ -313,8 +316,8 @@ const char* gemm_check(const GemmArgs& g) {
     return "gemm: the fused-LayerNorm epilogue runs on the ping-pong kernel only (tile 2, bf16 out, M and N multiples of 256)";
   if (g.res_index && g.epi != EPI_BIAS_LNRES && g.epi != EPI_BIAS_RES16) return "gemm: res_index only with the residual-row epilogues";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
-  if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 1 && g.tile != 2) return "gemm: tile must be 0 (auto), 1 / 2 (persistent), 128 or 256";
-  if ((g.tile == 1 || g.tile == 2) && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
+  if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 2) return "gemm: tile must be 0 (auto), 2 (ping-pong persistent), 128 or 256";
+  if (g.tile == 2 && !gemm_persist_ok(g)) return "gemm: persistent kernel needs M, N multiples of 256 and K of 128";
   return nullptr;
 }
 
@@ -329,11 +332,10 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
   }
-  if (g.res_index && (g.tile == 1 || g.tile == 2)) return hipErrorInvalidValue;
+  if (g.res_index && g.tile == 2) return hipErrorInvalidValue;
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
                       !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index && g.epi != EPI_BIAS_RES16))
     return launch_gemm8(g, st);
-  if (g.tile == 1) return launch_gemm_persist(g, st);
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_one<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_one<EPI_BIAS, true>(g, st);

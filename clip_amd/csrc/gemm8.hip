@@ -1,6 +1,6 @@
 // Ping-pong ("8-phase") persistent bf16 MFMA GEMM, 256x256x64 tiles, 8 waves:
 //   out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]),  M, N multiples of 256, K a multiple of 128.
-// Same math, LDS row image and epilogue fusions as gemm.hip / gemm_persist.hip (the dense layers of
+// Same math, LDS row image and epilogue fusions as gemm.hip (the dense layers of
 // transformers modeling_bert.py:175-177, 289-293, 334-337, 347-351 that sentclf/bert_model.py:79-88
 // runs); what changes is the schedule inside the workgroup:
 //
@@ -24,7 +24,7 @@
 //    counted (vmcnt(8) / vmcnt(4)): two half-tiles, or four, stay in flight across barriers, and
 //    what a phase reads was retired one barrier earlier.  The stream of half-tiles runs on across
 //    output tiles, so only a workgroup's first tile pays the global->LDS latency.
-//  * Epilogue as in gemm_persist.hip (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
+//  * Epilogue (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
 //    transpose, whole 128-byte row segments, non-temporal stores left in flight), through a 2-KiB
 //    scratch per wave beside the ring; the bias slice travels by LDS-DMA one tile ahead.
 #include <cstdlib>
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   char* scr = smem + RING + w * SCR;
   float* bias_lds = reinterpret_cast<float*>(smem + RING + 8 * SCR);
 
-  // ---- tile schedule (as gemm_persist.hip): the workgroups of one XCD walk one sequence
+  // ---- tile schedule: the workgroups of one XCD walk one sequence
   const int G = gridDim.x, per_x = G >> 3;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int n_tiles = tiles_m * tiles_n;
@@ -364,8 +364,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         }
       __syncthreads();
       LN_STAMP(3)
-      // (3) the workgroup's 256-column partial per row: published write-through (sc1 stores, every
-      // storing wave drained, barrier), then the flag (MI355X_MICROARCH.md, inter-workgroup hand-off)
+      // (3) the workgroup's 256-column partial per row, then the flag.  Ordering on gfx950, made explicit:
+      //   writer: the partials leave as agent-scope atomic stores (sc1: written through to the memory
+      //     side every XCD reads from, never parked in this XCD's L2); every storing wave waits
+      //     vmcnt(0) — stores are counted in vmcnt until the memory side has acknowledged them — and only
+      //     then reaches the workgroup barrier; thread 0 issues the flag store AFTER that barrier.  So
+      //     the flag cannot become visible before any partial of this tile (no release fence is needed:
+      //     a fence would add an L2 write-back of the whole XCD to every tile).
+      //   reader: the poll is an agent-scope atomic load (served from the memory side, not from this XCD's
+      //     L2); the partials are read AFTER the poller's barrier by agent-scope atomic loads as well,
+      //     issued in program order behind the flag observation (a wave issues its memory instructions
+      //     in order and no load is speculated past s_barrier), so they cannot return bytes older than
+      //     the flag.  Epochs make a stale flag of an earlier launch unequal to the awaited value.
       const int tile_id = tm * tiles_n + tn;
       if (tid < 256) {
         const float2 p0 = part_lds[tid], p1 = part_lds[256 + tid], p2 = part_lds[512 + tid], p3 = part_lds[768 + tid];
@@ -378,17 +388,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(lo.flags + tile_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && !(lo.test_drop && tile_id == 1))
+        __hip_atomic_store(lo.flags + tile_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       LN_STAMP(4)
       // (4) wait for the other column tiles of this row panel (lane 0 of wave k polls tile k), bounded:
-      // the partners are resident and one tile-time away at most, unless the GPU is shared
+      // the partners are resident and one tile-time away at most, unless the GPU is shared.  A timeout
+      // is sticky (bit 1 of *err stays set until the host polls it): once any tile has timed out, no later
+      // tile waits — the call is void anyway (its logits are turned into NaN) and must end quickly.
 #ifndef LNOUT_NOSYNC  // diagnostic builds
       if (lane == 0 && w < tiles_n && w != tn) {
         const uint32_t* f = lo.flags + tm * tiles_n + w;
         int spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lo.epoch) {
+        bool dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
+        while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lo.epoch) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > (1 << 23)) { atomicOr(lo.err, 2); break; }
+          if (++spins > (1 << 20)) { atomicOr(lo.err, 2); break; }
+          if ((spins & 255) == 0) dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
         }
       }
 #endif
@@ -553,21 +568,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 template <int EPI, bool OUT_F32, bool RES_TILED = false>
 hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
   auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED>;
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  static DeviceOnce once;  // per instantiation and device: function attribute + workgroup count
+  int n_cu = 0;
+  hipError_t e0 = once.get([&](int dev, int* val) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
     if (e != hipSuccess) return e;
-    int dev = 0, cus = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    int cus = 0;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-    n_cu = cus & ~7;
-    if (n_cu < 8) return hipErrorInvalidValue;
+    *val = cus & ~7;
+    if (*val < 8) return hipErrorInvalidValue;
     if (const char* cap = getenv("GEMM8_MAX_WGS")) {   // diagnostic: tools/dual_stream_bench.py
       const int c = atoi(cap) & ~7;
-      if (c >= 8 && c < n_cu) n_cu = c;
+      if (c >= 8 && c < *val) *val = c;
     }
-  }
+    return hipSuccess;
+  }, &n_cu);
+  if (e0 != hipSuccess) return e0;
   const int tiles_m = g.M / BM, tiles_n = g.N / BN, n_tiles = tiles_m * tiles_n;
   const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
   // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream

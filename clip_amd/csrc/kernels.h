@@ -23,7 +23,9 @@ struct LnOutArgs {         // EPI_BIAS_LNOUT
   uint32_t* flags;         // [tiles_m * tiles_n] last epoch published
   uint32_t epoch;          // differs from every earlier launch on these flags
   float eps;
-  int32_t* err;            // |= 2 when a partner tile's statistics did not arrive (bounded spin)
+  int32_t* err;            // |= 2 when a partner tile's statistics did not arrive (bounded spin); sticky:
+                           // while bit 1 is set no tile waits for its partners any more
+  uint32_t test_drop = 0;  // diagnostic (CLIP_AMD_TEST_DROP_PUBLISH=1): tile 1 never publishes its flag
 };
 
 struct GemmArgs {
@@ -35,7 +37,7 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres;
   int epi;
   bool out_f32;
-  int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 1: persistent 256x256 (gemm_persist.hip); 2: ping-pong persistent (gemm8.hip)
+  int tile = 0;  // 0 auto; 128 / 256: one tile per workgroup; 2: ping-pong persistent (gemm8.hip)
   bool f32_in = false;  // fp32 check mode: fp32 operands/residual, exact-fp32 MFMA (after `tile`: positional inits)
   // EPI_BIAS_LNRES: res = fp32 pre-LayerNorm rows [., N] (row stride ldres), and:
   const float* ln_stats = nullptr;   // [rows] (mean, rstd) pairs
@@ -43,12 +45,11 @@ struct GemmArgs {
   const float* ln_beta = nullptr;    // [N]
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
   int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles
-  LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
+  LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr, 0};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
 };
 const char* gemm_check(const GemmArgs& g);
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 bool gemm_persist_ok(const GemmArgs& g);
-hipError_t launch_gemm_persist(const GemmArgs& g, hipStream_t st);
 hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st);  // ping-pong schedule (gemm8.hip), same shapes
 
 // varlen self-attention over packed sequences; qkv [T, 3H] bf16 (q | k | v, heads of 64),
@@ -101,3 +102,33 @@ hipError_t launch_epilogue(const float* logits, const double* label_thresh, floa
 // mean over all elements of BCE-with-logits (ref: bert_model.py:97)
 hipError_t launch_bce_loss(const float* logits, const float* targets, int count, float* loss,
                            hipStream_t st);
+// err |= 4 unless cu_seqlens[0] == 0, every row has 1..max_seqlen tokens and cu_seqlens[n] == total_tokens
+hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
+                             int32_t* err, hipStream_t st);
+// logits[0..count) = NaN when *err != 0
+hipError_t launch_poison_logits(const int32_t* err, float* logits, int count, hipStream_t st);
+
+// Per-device one-time launch set-up (function attributes, CU count): a process may hold engines on
+// several GPUs, and two host threads may make their first call at once.
+#include <mutex>
+struct DeviceOnce {
+  static constexpr int MAX_DEV = 64;
+  std::mutex mu;
+  bool done[MAX_DEV] = {};
+  int value[MAX_DEV] = {};
+  // runs init(dev, &value) once per device; returns the device's value through *out
+  template <typename F>
+  hipError_t get(F&& init, int* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[dev]) {
+      if ((e = init(dev, &value[dev])) != hipSuccess) return e;
+      done[dev] = true;
+    }
+    *out = value[dev];
+    return hipSuccess;
+  }
+};

@@ -296,6 +296,31 @@ __global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__
   if (threadIdx.x == 0) loss[0] = (part[0] + part[1] + part[2] + part[3]) / (float)count;
 }
 
+// Guards of clip_forward_packed (no counterpart in the reference, whose padded tensors cannot be
+// inconsistent): the caller's cu_seqlens / max_seqlen are trusted by the attention launch geometry, so
+// a row longer than max_seqlen (or an offset table that does not end at total_tokens) would leave
+// stale ctx rows behind silently.  err |= 4 instead.
+__global__ __launch_bounds__(256) void check_rows_kernel(const int32_t* __restrict__ cu, int n_seqs,
+                                                         int total_tokens, int max_seqlen,
+                                                         int32_t* __restrict__ err) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_seqs) return;
+  const int len = cu[s + 1] - cu[s];
+  bool bad = len < 1 || len > max_seqlen;
+  if (s == 0) bad |= cu[0] != 0;
+  if (s == n_seqs - 1) bad |= cu[n_seqs] != total_tokens;
+  if (bad) atomicOr(err, 4);
+}
+
+// Last kernel of a forward: a non-zero device error word (fused-LayerNorm exchange timed out, bad row
+// table) turns every logit of the call into NaN, so that a void result cannot be mistaken for scores
+// even by a caller that never polls clip_poll_errors.
+__global__ __launch_bounds__(256) void poison_logits_kernel(const int32_t* __restrict__ err,
+                                                            float* __restrict__ logits, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count && *err != 0) logits[i] = __builtin_nanf("");
+}
+
 template <typename F>
 hipError_t ln_dispatch(int H, bool f32, F&& f) {
 #define LN_CASE(h, v, n) \
@@ -394,5 +419,19 @@ hipError_t launch_bce_loss(const float* logits, const float* targets, int count,
                            hipStream_t st) {
   if (count <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bce_loss_kernel, dim3(1), dim3(256), 0, st, logits, targets, count, loss);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
+                             int32_t* err, hipStream_t st) {
+  if (n_seqs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(check_rows_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, st, cu_seqlens, n_seqs,
+                     total_tokens, max_seqlen, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_poison_logits(const int32_t* err, float* logits, int count, hipStream_t st) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(poison_logits_kernel, dim3((count + 255) / 256), dim3(256), 0, st, err, logits, count);
   return hipGetLastError();
 }

@@ -57,6 +57,14 @@ class PackedRows:
         src = np.repeat(self.offsets[idx] - cu[:-1], lens) + np.arange(cu[-1])
         return self.flat[src], cu.astype(np.int32)
 
+    def gather_all(self, idx):
+        """The rows idx as one flat array + int64 offsets (one vectorised gather per chunk: the steps of
+        a length-sorted chunk are then contiguous slices)."""
+        lens = self.lens[idx].astype(np.int64)
+        cu = np.concatenate(([0], np.cumsum(lens)))
+        src = np.repeat(self.offsets[idx] - cu[:-1], lens) + np.arange(cu[-1])
+        return np.take(self.flat, src), cu
+
 
 def plan_steps(lens, tokens_per_step, max_rows_per_step):
     """Length bucketing: stable argsort by token count, then greedy steps bounded by tokens and rows.
@@ -92,6 +100,24 @@ class BulkScorer:
         self.max_rows_per_step = int(max_rows_per_step or model.max_seqs)
         if self.tokens_per_step > model.max_tokens or self.max_rows_per_step > model.max_seqs:
             raise ValueError("step size exceeds the model's engine workspace")
+        self._ws = None
+
+    def _workspace(self, dev, L):
+        """Per-scorer step buffers, allocated ONCE (the step loop allocates and pins nothing): device
+        tensors for one step (steps are serialised on the stream) and two pinned host staging buffers."""
+        if self._ws is not None and self._ws["dev"] == dev:
+            return self._ws
+        T, R = self.tokens_per_step, self.max_rows_per_step
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws = {"dev": dev, "ids": torch.empty(T, **i32), "cu": torch.empty(R + 1, **i32), "tt": torch.empty(T, **i32),
+              "pos": torch.empty(T, **i32), "focus": torch.empty(R, **i32),
+              "logits": torch.empty((R, L), dtype=torch.float32, device=dev), "stage": []}
+        for _ in range(2):
+            ids_h = torch.empty(T, dtype=torch.int32).pin_memory()
+            cu_h = torch.empty(R + 1, dtype=torch.int32).pin_memory()
+            ws["stage"].append((ids_h, cu_h, ids_h.numpy(), cu_h.numpy(), torch.cuda.Event()))
+        self._ws = ws
+        return ws
 
     def score(self, rows, doc_ids=None, sent_ixs=None):
         """rows: PackedRows or a list of int token-id arrays ([CLS] .. [SEP] layout of the
@@ -117,35 +143,35 @@ class BulkScorer:
         thr = None if self.label_threshs is None else torch.tensor(self.label_threshs, dtype=torch.float64, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         n_ctx_arg = self.n_ctx if self.n_ctx > 0 else -1
+        flat_s, off_s = rows.gather_all(order)          # the chunk in step order, gathered once
 
         with torch.cuda.device(dev):
             stream = _lib.stream_ptr()
             engine = model._ensure_engine()
-            for (a, b) in steps:
-                idx = order[a:b]
-                flat, cu = rows.gather(idx)
-                n, T = b - a, int(cu[-1])
-                ids_d = torch.from_numpy(flat).pin_memory().to(dev, non_blocking=True)
-                cu_d = torch.from_numpy(cu).pin_memory().to(dev, non_blocking=True)
-                tt_d = torch.empty(T, dtype=torch.int32, device=dev)
-                pos_d = torch.empty(T, dtype=torch.int32, device=dev)
-                focus_d = torch.empty(n, dtype=torch.int32, device=dev)
-                logits = torch.empty((n, L), dtype=torch.float32, device=dev)
+            w = self._workspace(dev, L)
+            ids_d, cu_d, tt_d, pos_d, focus_d, logits = (w[k] for k in ("ids", "cu", "tt", "pos", "focus", "logits"))
+            for k, (a, b) in enumerate(steps):
+                n, t0 = b - a, int(off_s[a])
+                T = int(off_s[b]) - t0
+                # two pinned staging buffers, reused: wait for the copy that last read this one
+                ids_h, cu_h, ids_hn, cu_hn, ev = w["stage"][k & 1]
+                ev.synchronize()
+                ids_hn[:T] = flat_s[t0:t0 + T]
+                np.subtract(off_s[a:b + 1], t0, out=cu_hn[:n + 1], casting="unsafe")
+                ids_d[:T].copy_(ids_h[:T], non_blocking=True)
+                cu_d[:n + 1].copy_(cu_h[:n + 1], non_blocking=True)
+                ev.record()
                 _lib.check(lib.clip_prepare_packed(_lib.ptr(ids_d), _lib.ptr(cu_d), n, self.sep_id, n_ctx_arg,
                                                    _lib.ptr(tt_d), _lib.ptr(pos_d), _lib.ptr(focus_d),
                                                    _lib.ptr(err), stream))
                 _lib.check(lib.clip_forward_packed(engine, _lib.ptr(ids_d), _lib.ptr(tt_d), _lib.ptr(pos_d),
                                                    _lib.ptr(cu_d), _lib.ptr(focus_d), n, T,
-                                                   int(rows.lens[idx[-1]]), model.head_kind, _lib.ptr(logits), stream))
+                                                   int(rows.lens[order[b - 1]]), model.head_kind, _lib.ptr(logits), stream))
                 _lib.check(lib.clip_epilogue(
                     _lib.ptr(logits), _lib.ptr(thr), self.any_threshold, n, L,
                     _lib.ptr(out_p[a:b]) if out_p is not None else None, _lib.ptr(out_max[a:b]),
                     _lib.ptr(out_lab[a:b]) if out_lab is not None else None, _lib.ptr(out_keep[a:b]), stream))
-            dev_flags = C.c_int32(0)
-            _lib.check(lib.clip_poll_errors(engine, C.byref(dev_flags)))
-            if dev_flags.value:
-                raise RuntimeError(f"engine error word {dev_flags.value}: a fused-LayerNorm exchange timed out "
-                                   "(GPU shared with other work?); results discarded")
+            _lib.poll_errors(engine)
             if int(err.item()) != 0:
                 raise TypeError(f"a row does not hold exactly {2 * self.n_ctx + 1} [SEP] tokens "
                                 "(sentclf/bert_model.py:51-55)")

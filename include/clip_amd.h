@@ -116,7 +116,7 @@ int clip_bce_loss(const float* dev_logits, const float* dev_targets, int32_t cou
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias): epi 0 bias, 1 bias+erf-GELU, 2 bias+residual, 3 bias+tanh
  * (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463). A, W, res are bf16; out bf16 or
  * fp32 (out_f32). Leading dimensions in elements. tile: 0 = choose, 128 / 256 = force that
- * workgroup tile edge, 1 / 2 = persistent / ping-pong persistent (M, N multiples of 256, K of 128). */
+ * workgroup tile edge, 2 = ping-pong persistent kernel (M, N multiples of 256, K of 128). */
 int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
                    const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
@@ -126,7 +126,7 @@ int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* de
  * (modeling_bert.py:292,350: what the reference adds as the residual) recomputed in the epilogue from
  * the producer's fp32 pre-LayerNorm rows `dev_res_pre`, their (mean, rstd) pairs `dev_ln_stats`
  * (clip_layernorm_stats) and the affine — so the residual stream never passes through bf16.
- * tile as clip_gemm_bf16 except 1; res_index only with the one-tile kernels (0, 128, 256). */
+ * tile as clip_gemm_bf16; res_index only with the one-tile kernels (0, 128, 256). */
 int clip_gemm_bf16_lnres(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
                          const float* dev_res_pre, const float* dev_ln_stats,
                          const float* dev_ln_gamma, const float* dev_ln_beta,
@@ -191,9 +191,16 @@ int clip_set_fused_layernorm(clip_engine* e, int32_t on);
 /* Packed tokens per forward call that fill the GPU in whole rounds of the fused-LayerNorm GEMMs
  * (<= max_tokens; = max_tokens when that flow is not in use).  The bulk driver sizes its steps by it. */
 int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens);
-/* Device-side error word of the engine since the last poll (synchronises with its stream work):
- * bit 1 = a fused-LayerNorm tile's partner statistics did not arrive within the spin bound (a GPU
- * shared with work that kept a workgroup from being scheduled); results of that call are void. */
+/* Device-side error word of the engine since the last poll (read behind the latest forward on that
+ * forward's stream, then cleared):
+ *   bit 1 (2) = a fused-LayerNorm tile's partner statistics did not arrive within the spin bound (a GPU
+ *               shared with work that kept a workgroup from being scheduled; the fused flow needs its
+ *               3 column-tile workgroups co-resident).  Sticky on the device: while it is set no later
+ *               tile waits, so a void job ends quickly;
+ *   bit 2 (4) = the row table of a forward was inconsistent (cu_seqlens[0] != 0, a row of < 1 or
+ *               > max_seqlen tokens, cu_seqlens[n_seqs] != total_tokens).
+ * While the word is non-zero every clip_forward_packed writes NaN logits: results of those calls are
+ * void whether or not the caller polls. */
 int clip_poll_errors(clip_engine* e, int32_t* host_flags);
 
 /* HIP-event timing of the kernels inside clip_forward_packed, for bench.py's roofline figure (no

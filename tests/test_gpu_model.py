@@ -176,3 +176,62 @@ def test_fused_layernorm_equals_unfused(golden, name):
     _lib.check(_lib.load().clip_set_fused_layernorm(h, 1))
     again, _ = run_padded(model, g)
     assert np.array_equal(fused, again)
+
+
+def test_inconsistent_row_table_voids_the_call():
+    """The packed ABI trusts the caller's cu_seqlens / max_seqlen for its launch geometry: a row longer
+    than max_seqlen sets bit 2 of the engine's error word, the logits come back NaN, and the host
+    mirrors raise (no counterpart in the reference: padded tensors cannot be inconsistent)."""
+    import ctypes as C
+    from clip_amd import _lib
+    from conftest import load_golden
+    g = load_golden("tiny_ctx")
+    model = build_model(g)
+    h = model._ensure_engine()
+    lib = _lib.load()
+    rows = g["rows"][:4]
+    lens = np.array([len(r) for r in rows], np.int32)
+    ids = torch.from_numpy(np.concatenate(rows).astype(np.int32)).cuda()
+    cu = torch.from_numpy(np.concatenate(([0], np.cumsum(lens))).astype(np.int32)).cuda()
+    pos = torch.cat([torch.arange(int(l), dtype=torch.int32) for l in lens]).cuda()
+    focus = model.focus_index(ids, cu)
+    logits = torch.zeros((4, model.num_labels), device="cuda")
+    _lib.check(lib.clip_forward_packed(h, _lib.ptr(ids), None, _lib.ptr(pos), _lib.ptr(cu), _lib.ptr(focus), 4,
+                                       int(lens.sum()), int(lens.max()) - 1, 0, _lib.ptr(logits), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isnan(logits).all()
+    with pytest.raises(ValueError, match="row table"):
+        _lib.poll_errors(h)
+    # the poll cleared the word: the same call with the true maximum is good again
+    _lib.check(lib.clip_forward_packed(h, _lib.ptr(ids), None, _lib.ptr(pos), _lib.ptr(cu), _lib.ptr(focus), 4,
+                                       int(lens.sum()), int(lens.max()), 0, _lib.ptr(logits), _lib.stream_ptr()))
+    _lib.poll_errors(h)
+    assert torch.isfinite(logits).all()
+
+
+def test_fused_layernorm_timeout_is_loud(monkeypatch):
+    """A fused-LayerNorm tile whose partner never publishes (forced by the diagnostic switch
+    CLIP_AMD_TEST_DROP_PUBLISH) must not return scores: bounded wait, sticky abort for the later tiles,
+    NaN logits, and the nn.Module forward, forward_packed and BulkScorer.score all raise."""
+    import time
+    from clip_amd import scoring, synth
+    from clip_amd.bert_model import BertSequenceMultilabelClassificationContext
+    from clip_amd.config import BertConfig
+    from clip_amd.weights import procedural_state_dict
+    monkeypatch.setenv("CLIP_AMD_TEST_DROP_PUBLISH", "1")
+    monkeypatch.setenv("CLIP_AMD_FUSED_LN", "1")
+    cfg = BertConfig(vocab_size=2000, hidden_size=512, num_hidden_layers=3, num_attention_heads=8, intermediate_size=1024)
+    model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=16384, max_seqs=512)
+    model.load_state_dict(procedural_state_dict(cfg, 3))
+    model.to("cuda").eval()
+    model.set_sep_token_id(102); model.set_n_context_sentences(2); model.set_task("multilabel")
+    rows = synth.context_rows(300, 2, cfg.vocab_size, max_len=96, seed=11)       # several row panels per GEMM
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="fused-LayerNorm exchange timed out"):
+        scoring.BulkScorer(model).score(rows)
+    assert time.perf_counter() - t0 < 60          # the first tiles wait out their bound, the rest skip
+    ids, mask = O.pad_batch(rows[:8])
+    tt = O.token_type_ids_from_seps(ids, 102, 2)
+    with pytest.raises(RuntimeError, match="timed out"):
+        model(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda())
+    model._drop_engine()

@@ -1,0 +1,50 @@
+"""The N > 1 path as the driver starts it: `bench.py --gpus 2` and `python -m clip_amd.job --gpus 2`
+launch their own ranks (clip_amd/launch.py).  With two visible MI355X the ranks use RCCL (backend
+"nccl"), one card each; on a one-GPU box both ranks share the card, so the process group is gloo and
+the fused-LayerNorm flow (which assumes the card is not shared) is off — the same for the one-rank
+run it is compared with.  Replaces the single device of sentclf/apply_bert_unlabeled.py:71."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 2:
+        env["CLIP_AMD_FUSED_LN"] = "0"
+    return env
+
+
+def _run(args):
+    p = subprocess.run([sys.executable, "-u", *args], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    line = _run(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows-per-step", "85",
+                 "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2
+    assert line["dist"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert line["value"] > 0 and line["scaling"] == "weak"
+    # whole-job value = rows of BOTH ranks over the slowest rank's time
+    assert abs(line["value"] - 2 * 85 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 1e-3
+
+
+def test_job_two_ranks_topk_file_identical_to_one_rank(tmp_path):
+    common = ["-m", "clip_amd.job", "--config", "C4", "--rows", "6000", "--chunk-rows", "1500", "--topk", "300",
+              "--tokens-per-step", "32768"]
+    one = _run(common + ["--out", str(tmp_path / "one.csv")])
+    two = _run(common + ["--gpus", "2", "--out", str(tmp_path / "two.csv")])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["rows"] == two["rows"] == 6000 and one["kept"] == two["kept"] and one["tokens"] == two["tokens"]
+    a, b = (tmp_path / "one.csv").read_bytes(), (tmp_path / "two.csv").read_bytes()
+    assert a == b and a.count(b"\n") == 301
