@@ -44,6 +44,8 @@ SIGNATURES = {
     "clip_gemm_bf16_lnres": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_bf16_lnout": [_p, _p, _p, _p, _i32, _p, _p, _f, _p, _p, _p, _p, C.c_uint32, _p,
                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_gemm_bf16_lnout_noalloc": [_p, _p, _p, _p, _i32, _p, _p, _f, _p, _p, _p,
+                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "clip_layernorm": [_p, _p, _p, _f, _p, _i32, _i32, _p],

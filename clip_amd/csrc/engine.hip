@@ -188,7 +188,19 @@ const std::vector<float>* find(clip_engine* e, const std::string& k, size_t nume
 
 }  // namespace
 
+// ---- static scratch of the entry point that allocates nothing (clip_gemm_bf16_lnout_noalloc): the
+// fused-LayerNorm exchange buffers ((sum, sumsq) pairs per tile row + one flag per tile) for up to
+// CLIP_NOALLOC_MAX_TILES 256x256 output tiles.  Each GPU the library runs on holds its own copy of the
+// array (4.2 MB) until the process ends; host code reaches it only through hipGetSymbolAddress.
+constexpr size_t SCRATCH_FLAGS_OFF = (size_t)CLIP_NOALLOC_MAX_TILES * 256 * 8;
+constexpr size_t SCRATCH_BYTES = SCRATCH_FLAGS_OFF + (size_t)CLIP_NOALLOC_MAX_TILES * 4;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
 namespace {
+struct ScratchDev { unsigned char* ptr = nullptr; uint32_t epoch = 0; };
+ScratchDev g_scratch_dev[64];
+std::mutex g_scratch_mu;
+
 struct ProfScope {
   clip_engine* e; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
   ProfScope(clip_engine* e_, int kind_, hipStream_t st_) : e(e_), kind(kind_), st(st_) {
@@ -684,6 +696,49 @@ int clip_gemm_bf16_lnout(const uint16_t* A, const uint16_t* W, const float* bias
   if (!res16 || !xres_out || !part || !flags || !err || N / 256 > 8)
     return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout: null buffer, or more than 8 column tiles");
   HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_gemm_bf16_lnout_noalloc(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res16,
+                                 int32_t res_tiled, const float* gamma, const float* beta, float eps,
+                                 uint16_t* x_out, uint16_t* xres_out, int32_t* err, int32_t M, int32_t N,
+                                 int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, void* stream) {
+  GemmArgs g{A, W, bias, res16, x_out, M, N, K, lda, ldw, ldo, ldres, EPI_BIAS_LNOUT, false, 2};
+  g.ln_gamma = gamma; g.ln_beta = beta;
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  if (!res16 || !xres_out || !err || N / 256 > 8)
+    return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout_noalloc: null buffer, or more than 8 column tiles");
+  const long tiles = (long)(M / 256) * (N / 256);
+  if (tiles > CLIP_NOALLOC_MAX_TILES)
+    return fail(CLIP_ERR_CAPACITY, "clip_gemm_bf16_lnout_noalloc: %ld tiles of 256x256 exceed the static scratch (%d tiles)",
+                tiles, CLIP_NOALLOC_MAX_TILES);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout_noalloc: device %d", dev);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t epoch;
+  unsigned char* base;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchDev& sd = g_scratch_dev[dev];
+    bool clear = false;
+    if (!sd.ptr) {
+      // once per device, with that device current: the device address of THIS GPU's copy of the array
+      // (the array's name is a host-side stand-in, never a kernel argument)
+      void* p = nullptr;
+      HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      sd.ptr = static_cast<unsigned char*>(p);
+      clear = true;
+    }
+    if (++sd.epoch == 0) { sd.epoch = 1; clear = true; }  // epoch wrap: stale flags could match again
+    base = sd.ptr;
+    epoch = sd.epoch;
+    // the flags must start below every epoch (the array keeps the last call's contents otherwise)
+    if (clear) HIP_TRY(hipMemsetAsync(base + SCRATCH_FLAGS_OFF, 0, (size_t)CLIP_NOALLOC_MAX_TILES * 4, st));
+  }
+  g.lnout = LnOutArgs{xres_out, res_tiled != 0, reinterpret_cast<float*>(base),
+                      reinterpret_cast<uint32_t*>(base + SCRATCH_FLAGS_OFF), epoch, eps, err, 0};
+  HIP_TRY(launch_gemm(g, st));
   return CLIP_OK;
 }
 

@@ -152,6 +152,21 @@ int clip_gemm_bf16_lnout(const uint16_t* dev_A, const uint16_t* dev_W, const flo
                          float eps, uint16_t* dev_x_out, uint16_t* dev_xres_out, float* dev_part,
                          uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M, int32_t N,
                          int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, void* stream);
+/* clip_gemm_bf16_lnout for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, kernel and
+ * result bits as clip_gemm_bf16_lnout, minus dev_part / dev_flags / epoch: the exchange buffers live in
+ * a static device array inside the library (4.2 MB per GPU, held until the process ends) and the
+ * epoch is kept per device by the library.  Calls no hipMalloc / hipFree or allocating routine; the first
+ * call on a device resolves the array's address (hipGetSymbolAddress) and clears its flags on `stream`.
+ * Limit: (M/256)*(N/256) <= CLIP_NOALLOC_MAX_TILES, else CLIP_ERR_CAPACITY.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race on it —
+ * serialise them; calls on different GPUs are independent.  Runs on the current device. */
+#define CLIP_NOALLOC_MAX_TILES 2048
+int clip_gemm_bf16_lnout_noalloc(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                                 const uint16_t* dev_res16, int32_t res_tiled, const float* dev_gamma,
+                                 const float* dev_beta, float eps, uint16_t* dev_x_out, uint16_t* dev_xres_out,
+                                 int32_t* dev_err, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                                 int32_t ldo, int32_t ldres, void* stream);
 /* fp32 check mode of the same GEMM kernel: fp32 operands, residual and output, exact-fp32 MFMA
  * (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  K a multiple of 32. */
 int clip_gemm_f32(const float* dev_A, const float* dev_W, const float* dev_bias,
