@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("CLIP_AMD_LIB") or os.path.join(_HERE, "lib", "libclip
 CLIP_OK, CLIP_ERR_ARG, CLIP_ERR_HIP, CLIP_ERR_STATE, CLIP_ERR_CAPACITY, CLIP_ERR_SEP_COUNT = 0, -1, -2, -3, -4, -5
 KINDS = ("embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up",
          "gemm_ffn_down", "head", "last_layer_rows")
-PRECISION_BF16, PRECISION_FP32 = 0, 1
+PRECISION_BF16, PRECISION_FP32, PRECISION_F16 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH = 0, 1, 2, 3
 
 
@@ -41,6 +41,7 @@ SIGNATURES = {
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
     "clip_gemm_bf16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_gemm_f16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_bf16_lnres": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_bf16_lnout": [_p, _p, _p, _p, _i32, _p, _p, _f, _p, _p, _p, _p, C.c_uint32, _p,
                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
@@ -48,6 +49,7 @@ SIGNATURES = {
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
+    "clip_attention_varlen_f16": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "clip_layernorm": [_p, _p, _p, _f, _p, _i32, _i32, _p],
     "clip_layernorm_stats": [_p, _p, _p, _f, _p, _p, _i32, _i32, _p],
     "clip_embed_layernorm": [_p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _p],

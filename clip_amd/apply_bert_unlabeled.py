@@ -52,6 +52,8 @@ def main(argv=None):
                         help="rows scored per chunk of whole documents (bounds host memory; chunk c -> rank c mod world)")
     parser.add_argument("--save_rows", type=str, default=None,
                         help="write the tokenised rows as a columnar directory (tokenise once, score many times)")
+    parser.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
+                        help="operand type of the GEMM / attention kernels (clip_set_precision)")
     parser.add_argument("--gpus", type=int, default=1,
                         help="ranks to start, one per MI355X (documents are sharded; ignored under torchrun)")
     parser.add_argument("--tokenize_only", action="store_true", help="stop after --save_rows (needs no GPU)")
@@ -118,6 +120,7 @@ def main(argv=None):
     else:
         sd = torch.load(args.local_weights, map_location="cpu", weights_only=True)       # :78
     model.load_state_dict(sd)                                                          # :79
+    model.set_precision(args.precision)
     model.to(device).eval()                                                            # :72,100
     if args.n_context_sentences > 0:
         model.set_sep_token_id(sep_id)                                                 # :74

@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   const bool wave_live = q0 < len;  // wave-uniform
 
   // Q^T fragments (B operand of S^T): lane holds Q[q0 + l31][16 s + 8 h + j]
-  bf16x8_t qf[4];
+  opx8_t qf[4];
   {
     const int qr = min(q0 + l31, len - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      qf[s] = *reinterpret_cast<const bf16x8_t*>(qbase + (size_t)qr * ld + 16 * s + 8 * h);
+      qf[s] = *reinterpret_cast<const opx8_t*>(qbase + (size_t)qr * ld + 16 * s + 8 * h);
   }
 
   // staging map: thread -> (row, chunk) for two 16-B chunks of K and of V per tile
@@ -104,13 +104,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
       const int row = kb * 32 + l31;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+        const opx8_t kf = *reinterpret_cast<const opx8_t*>(
             k_lds + row * 128 + swz128(row, 2 * ks + h) * 16);
         if (ks == 0) {
           const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], zero, 0, 0, 0);
+          s[kb] = MFMA_32x32x16(kf, qf[ks], zero);
         } else {
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+          s[kb] = MFMA_32x32x16(kf, qf[ks], s[kb]);
         }
       }
     }
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        bf16x8_t pf;
+        opx8_t pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)p[8 * ss + j];
+        for (int j = 0; j < 8; ++j) pf[j] = (op_t)p[8 * ss + j];
         // element j of half h <-> key 32 kb + 16 ss + 8 (j>>2) + 4 h + (j&3)
         const int key0 = kb * 32 + 16 * ss + 4 * h;
 #pragma unroll
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
           s16x8_t vv;
           vv[0] = va[0]; vv[1] = va[1]; vv[2] = va[2]; vv[3] = va[3];
           vv[4] = vb[0]; vv[5] = vb[1]; vv[6] = vb[2]; vv[7] = vb[3];
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8_t*>(&vv), pf,
-                                                          o[db], 0, 0, 0);
+          o[db] = MFMA_32x32x16(*reinterpret_cast<opx8_t*>(&vv), pf,
+                                                          o[db]);
         }
       }
     }
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * db + 8 * g + 4 * h;
         *reinterpret_cast<uint2*>(dst + d) =
-            make_uint2(pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                       pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+            make_uint2(pack_op2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                       pack_op2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
       }
   }
 }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   const int ld = 3 * hidden;
   const bf16_t* kbase = qkv + (size_t)beg * ld + hidden + head * HD;
   const bf16_t* vbase = kbase + hidden;
-  q_s[lane] = bf16_to_f32(q_rows ? q_rows[(size_t)seq * hidden + head * HD + lane]
+  q_s[lane] = op_to_f32(q_rows ? q_rows[(size_t)seq * hidden + head * HD + lane]
                                  : qkv[(size_t)focus[seq] * ld + head * HD + lane]);
   __syncthreads();
   float sc[8];
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
         const uint32_t wds[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          d = fmaf(__uint_as_float(wds[e] << 16), q_s[c * 8 + 2 * e], d);
-          d = fmaf(__uint_as_float(wds[e] & 0xffff0000u), q_s[c * 8 + 2 * e + 1], d);
+          d = fmaf(op2_lo(wds[e]), q_s[c * 8 + 2 * e], d);
+          d = fmaf(op2_hi(wds[e]), q_s[c * 8 + 2 * e + 1], d);
         }
       }
       d *= LOG2E;
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   sum = wave_sum(sum);
   __syncthreads();
   float o = 0.f;
-  for (int key = 0; key < len; ++key) o = fmaf(p_s[key], bf16_to_f32(vbase[(size_t)key * ld + lane]), o);
-  ctx_rows[(size_t)seq * hidden + head * HD + lane] = f32_to_bf16(o / sum);
+  for (int key = 0; key < len; ++key) o = fmaf(p_s[key], op_to_f32(vbase[(size_t)key * ld + lane]), o);
+  ctx_rows[(size_t)seq * hidden + head * HD + lane] = f32_to_op(o / sum);
 }
 
 // fp32 check mode: the same softmax(q k^T) v on fp32 q/k/v with fp32 arithmetic throughout (no
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(128) void attention_f32_kernel(const float* __restr
 
 }  // namespace
 
+#if !CLIP_OPERAND_F16
 hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, float* ctx, int n_seqs,
                                 int max_seqlen, int n_heads, int hidden, hipStream_t st) {
   if (n_seqs <= 0) return hipSuccess;
@@ -366,7 +367,9 @@ hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, flo
   return hipGetLastError();
 }
 
-hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
+#endif
+
+hipError_t KSET::launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
                                   const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
                                   int hidden, hipStream_t st, const bf16_t* q_rows) {
   if (n_seqs <= 0) return hipSuccess;
@@ -376,7 +379,7 @@ hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
   return hipGetLastError();
 }
 
-hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
+hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
                             int max_seqlen, int n_heads, int hidden, hipStream_t st) {
   if (n_seqs <= 0) return hipSuccess;
   if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;

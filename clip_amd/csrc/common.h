@@ -3,9 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef uint16_t bf16_t;  // raw 16-bit operand bits (bf16, or fp16 in the f16 kernel set)
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -14,16 +12,45 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+// ---- the 16-bit OPERAND type of the MFMA kernels.  Every kernel file is compiled twice: into the
+// bf16 kernel set (struct k_bf16, the default numerics setting) and, with -DCLIP_OPERAND_F16=1, into
+// the fp16 kernel set (struct k_f16: v_mfma_*_f16 at the same rate, 11 significant bits instead of 8,
+// fp16's range — CLIP_PRECISION_F16).  Same code, same LDS images, same schedules; only the element
+// type, the MFMA opcode and the conversions below differ.
+#ifndef CLIP_OPERAND_F16
+#define CLIP_OPERAND_F16 0
+#endif
+#if CLIP_OPERAND_F16
+#define KSET k_f16
+typedef _Float16 op_t;
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op_to_f32(bf16_t v) {
+  return (float)*reinterpret_cast<const _Float16*>(&v);
+}
+// the two halves of a 32-bit word holding two operands
+__device__ __forceinline__ float op2_lo(uint32_t w) { return op_to_f32((bf16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float op2_hi(uint32_t w) { return op_to_f32((bf16_t)(w >> 16)); }
+#else
+#define KSET k_bf16
+typedef __bf16 op_t;
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op_to_f32(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
-__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
-  __bf16 b = (__bf16)x;
+__device__ __forceinline__ float op2_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float op2_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+typedef __attribute__((ext_vector_type(8))) op_t opx8_t;
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950 and keeps
+// NaN a NaN (fp16: a value beyond +-65504 becomes inf)
+__device__ __forceinline__ bf16_t f32_to_op(float x) {
+  op_t b = (op_t)x;
   return *reinterpret_cast<bf16_t*>(&b);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
+  return (uint32_t)f32_to_op(lo) | ((uint32_t)f32_to_op(hi) << 16);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

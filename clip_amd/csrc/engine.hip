@@ -63,6 +63,7 @@ struct clip_engine {
   // numerics setting of the SAME kernels (clip_set_precision): false = bf16 operands / fp32
   // accumulation, true = fp32 check mode (fp32 weights, activations and MFMA)
   bool f32 = false;
+  bool f16 = false;  // CLIP_PRECISION_F16: the k_f16 kernel set (fp16 operands, same MFMA rate, 11-bit significand)
   // workspace (allocated by clip_finalize_weights, element size by precision)
   void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
        *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr, *xf_rows = nullptr, *q_rows = nullptr;
@@ -116,9 +117,25 @@ int upload_bf16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scal
   return CLIP_OK;
 }
 
-// a GEMM weight: bf16 (rounded once, here) or fp32 as loaded; the first n_first elements scaled
+int upload_f16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scale_first, size_t n_first) {
+  std::vector<uint16_t> tmp(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float v = i < n_first ? h[i] * scale_first : h[i];
+    if (std::fabs(v) > 65504.f)
+      return fail(CLIP_ERR_ARG, "a weight (%g) is outside fp16's range: use CLIP_PRECISION_BF16 for this checkpoint", v);
+    const _Float16 hv = (_Float16)v;  // round to nearest even
+    memcpy(&tmp[i], &hv, 2);
+  }
+  int rc = dev_alloc(e, (void**)d, n * 2);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(*d, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CLIP_OK;
+}
+
+// a GEMM weight: bf16 / fp16 (rounded once, here) or fp32 as loaded; the first n_first elements scaled
 int upload_w(clip_engine* e, const float* h, size_t n, void** d, float scale_first = 1.f,
              size_t n_first = 0) {
+  if (e->f16) return upload_f16(e, h, n, reinterpret_cast<bf16_t**>(d), scale_first, n_first);
   if (!e->f32) return upload_bf16(e, h, n, reinterpret_cast<bf16_t**>(d), scale_first, n_first);
   std::vector<float> tmp(h, h + n);
   for (size_t i = 0; i < n_first; ++i) tmp[i] *= scale_first;
@@ -223,10 +240,218 @@ struct ProfScope {
 };
 }  // namespace
 
+namespace {
+
+// One forward on the kernel set K (k_bf16: bf16 operands and the fp32 check mode; k_f16: fp16 operands)
+template <class KS>
+int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_ids,
+                        const int32_t* pos_ids, const int32_t* cu, const int32_t* focus,
+                        int32_t n_seqs, int32_t T, int32_t max_seqlen, int32_t head_kind,
+                        float* logits, void* stream) {
+  if (!e || !ids || !pos_ids || !cu || !focus || !logits)
+    return fail(CLIP_ERR_ARG, "clip_forward_packed: null argument");
+  if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_packed: weights not finalized");
+  if (n_seqs == 0 || T == 0) return CLIP_OK;
+  if (n_seqs < 0 || T < 0 || max_seqlen < 1 || max_seqlen > e->cfg.max_position)
+    return fail(CLIP_ERR_ARG, "clip_forward_packed: bad sizes (n_seqs %d, tokens %d, max_seqlen %d)",
+                n_seqs, T, max_seqlen);
+  if (n_seqs > e->cfg.max_seqs || T > e->cfg.max_tokens)
+    return fail(CLIP_ERR_CAPACITY, "clip_forward_packed: %d seqs / %d tokens exceed the workspace (%d / %d)",
+                n_seqs, T, e->cfg.max_seqs, e->cfg.max_tokens);
+  if (head_kind == 1 && !e->wpool)
+    return fail(CLIP_ERR_STATE, "clip_forward_packed: pooler weights were not loaded");
+  if (head_kind != 0 && head_kind != 1) return fail(CLIP_ERR_ARG, "clip_forward_packed: head_kind");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  e->last_stream = st;
+  const clip_config& c = e->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size;
+  // the row table is the caller's: a row beyond max_seqlen or a table that does not end at T sets bit 2
+  HIP_TRY(launch_check_rows(cu, n_seqs, T, max_seqlen, e->dev_err, st));
+
+  const bool f32 = e->f32;
+  // Residual operands.  bf16 setting: the GEMM epilogue re-derives the fp32 LayerNorm output from the
+  // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
+  // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
+  // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
+  const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
+  int cur = 0;
+  const float *g_prev = e->embg, *b_prev = e->embb;
+  // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
+  // rewrites); the very first residual is the embedding LayerNorm's row-major copy
+  bool first_res = true;
+  auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
+                     const float* beta) {
+    GemmArgs a{A, W, bias, first_res ? e->xres_rm : e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
+    a.ln_gamma = gamma; a.ln_beta = beta;
+    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err,
+                        e->test_drop ? 1u : 0u};
+    first_res = false;
+    return KS::launch_gemm(a, st);
+  };
+  auto res_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* pre_in,
+                      const float* stats_in, float* pre_out, const int32_t* index) {
+    GemmArgs a{A, W, bias, f32 ? e->x : (const void*)pre_in, pre_out, M, H, K, K, K, H, H,
+               f32 ? EPI_BIAS_RES : EPI_BIAS_LNRES, true, 0, f32};
+    if (!f32) { a.ln_stats = stats_in; a.ln_gamma = g_prev; a.ln_beta = b_prev; a.res_index = index; }
+    return KS::launch_gemm(a, st);
+  };
+  {
+    ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
+    HIP_TRY(KS::launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
+                            c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
+                            c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
+                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres_rm : nullptr));
+  }
+  GemmArgs g;
+  // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
+  const int Tg = f32 ? T : (T + 255) / 256 * 256;
+  // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
+  // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
+  const bool trim = e->trim_last && c.max_position <= 512 && !f32;
+  for (int i = 0; i < c.num_layers; ++i) {
+    const LayerW& L = e->layers[i];
+    if (trim && i == c.num_layers - 1) {
+      // The rest of the last layer runs on n_seqs rows: only the pooled token's q is ever read, so the
+      // all-token GEMM stops at K and V (the k|v rows of the fused weight, the k|v columns of qkv) and q
+      // is projected for the gathered focus rows alone (same bits: a row's result does not depend on the
+      // GEMM kernel that computes it).
+      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
+      g = GemmArgs{e->x, static_cast<bf16_t*>(L.wqkv) + (size_t)H * H, L.bqkv + H, nullptr,
+                   static_cast<bf16_t*>(e->qkv) + H, Tg, 2 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      HIP_TRY(KS::launch_gemm(g, st));
+      HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
+      g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
+      HIP_TRY(KS::launch_gemm(g, st));
+      break;
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
+      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, f32, 0, f32};
+      HIP_TRY(KS::launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_ATTENTION, st);
+      if (f32)
+        HIP_TRY(launch_attention_f32(static_cast<const float*>(e->qkv), cu, static_cast<float*>(e->ctx),
+                                     n_seqs, max_seqlen, c.num_heads, H, st));
+      else
+        HIP_TRY(KS::launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
+                                 n_seqs, max_seqlen, c.num_heads, H, st));
+    }
+    if (fused) {
+      ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
+      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b));
+    } else {
+      {
+        ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
+        HIP_TRY(res_gemm(e->ctx, L.wo, L.bo, Tg, H, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
+      }
+      cur ^= 1;
+      {
+        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+        HIP_TRY(KS::launch_layernorm(e->pre[cur], L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32,
+                                 f32 ? nullptr : e->stats[cur]));
+      }
+    }
+    g_prev = L.ln1g; b_prev = L.ln1b;
+    {
+      ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
+      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
+      HIP_TRY(KS::launch_gemm(g, st));
+    }
+    if (fused) {
+      ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
+      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b));
+    } else {
+      {
+        ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
+        HIP_TRY(res_gemm(e->mid, L.wo2, L.bo2, Tg, I, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
+      }
+      cur ^= 1;
+      {
+        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
+        HIP_TRY(KS::launch_layernorm(e->pre[cur], L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32,
+                                 f32 ? nullptr : e->stats[cur]));
+      }
+    }
+    g_prev = L.ln2g; b_prev = L.ln2b;
+  }
+  if (trim) {
+    // ref: sentclf/bert_model.py:52-58 / :234 consume ONE hidden row per sentence, so past the last
+    // layer's K/V projection only that row is computed (SURVEY.md a9): M = n_seqs instead of T.
+    const LayerW& L = e->layers[c.num_layers - 1];
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(KS::launch_attention_focus(static_cast<const bf16_t*>(e->qkv), cu, focus,
+                                     static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st,
+                                     static_cast<const bf16_t*>(e->q_rows)));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
+      if (fused) {
+        // (a one-layer model trims its only layer: the residual is still the embedding's row-major copy)
+        GemmArgs a{e->ctx_rows, L.wo, L.bo, first_res ? e->xres_rm : e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H,
+                   EPI_BIAS_RES16, true};
+        a.res_index = focus;
+        a.res_tiles_n = first_res ? 0 : H / 256;
+        HIP_TRY(KS::launch_gemm(a, st));
+      } else {
+        HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
+      }
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(KS::launch_layernorm(e->pre_rows[0], L.ln1g, L.ln1b, c.layer_norm_eps, e->rows, n_seqs, H, st,
+                               false, e->stats_rows[0]));
+    }
+    g_prev = L.ln1g; b_prev = L.ln1b;
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      g = GemmArgs{e->rows, L.wi, L.bi, nullptr, e->mid_rows, n_seqs, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
+      HIP_TRY(KS::launch_gemm(g, st));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(res_gemm(e->mid_rows, L.wo2, L.bo2, n_seqs, I, e->pre_rows[0], e->stats_rows[0], e->pre_rows[1], nullptr));
+    }
+    {
+      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
+      HIP_TRY(KS::launch_layernorm(e->pre_rows[1], L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
+    }
+  }
+  ProfScope ps_head(e, CLIP_KIND_HEAD, st);
+  if (trim) {
+    if (head_kind == 0) {
+      HIP_TRY(KS::launch_classifier(e->rows, nullptr, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
+    } else {
+      g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
+                   EPI_BIAS_TANH, false};
+      HIP_TRY(KS::launch_gemm(g, st));
+      HIP_TRY(KS::launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
+                                c.num_labels, st));
+    }
+  } else if (head_kind == 0) {
+    HIP_TRY(KS::launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st, f32));
+  } else {
+    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st, f32));
+    g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
+                 EPI_BIAS_TANH, f32, 0, f32};
+    HIP_TRY(KS::launch_gemm(g, st));
+    HIP_TRY(KS::launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
+                              c.num_labels, st, f32));
+  }
+  // a void call (device error word set) must not look like scores: NaN logits, poll or no poll
+  HIP_TRY(launch_poison_logits(e->dev_err, logits, n_seqs * c.num_labels, st));
+  return CLIP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* clip_last_error(void) { return g_err.c_str(); }
-int clip_abi_version(void) { return 1; }
+int clip_abi_version(void) { return 2; }
 
 int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   if (!c || !out) return fail(CLIP_ERR_ARG, "clip_create: null argument");
@@ -260,11 +485,12 @@ int clip_destroy(clip_engine* e) {
 
 int clip_set_precision(clip_engine* e, int32_t precision) {
   if (!e) return fail(CLIP_ERR_ARG, "clip_set_precision: null engine");
-  if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32)
+  if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32 && precision != CLIP_PRECISION_F16)
     return fail(CLIP_ERR_ARG, "clip_set_precision: unknown precision %d", precision);
   if (e->finalized || e->stats_rows[1])
     return fail(CLIP_ERR_STATE, "clip_set_precision: call before clip_finalize_weights");
   e->f32 = precision == CLIP_PRECISION_FP32;
+  e->f16 = precision == CLIP_PRECISION_F16;
   return CLIP_OK;
 }
 
@@ -383,202 +609,9 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
                         const int32_t* pos_ids, const int32_t* cu, const int32_t* focus,
                         int32_t n_seqs, int32_t T, int32_t max_seqlen, int32_t head_kind,
                         float* logits, void* stream) {
-  if (!e || !ids || !pos_ids || !cu || !focus || !logits)
-    return fail(CLIP_ERR_ARG, "clip_forward_packed: null argument");
-  if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_packed: weights not finalized");
-  if (n_seqs == 0 || T == 0) return CLIP_OK;
-  if (n_seqs < 0 || T < 0 || max_seqlen < 1 || max_seqlen > e->cfg.max_position)
-    return fail(CLIP_ERR_ARG, "clip_forward_packed: bad sizes (n_seqs %d, tokens %d, max_seqlen %d)",
-                n_seqs, T, max_seqlen);
-  if (n_seqs > e->cfg.max_seqs || T > e->cfg.max_tokens)
-    return fail(CLIP_ERR_CAPACITY, "clip_forward_packed: %d seqs / %d tokens exceed the workspace (%d / %d)",
-                n_seqs, T, e->cfg.max_seqs, e->cfg.max_tokens);
-  if (head_kind == 1 && !e->wpool)
-    return fail(CLIP_ERR_STATE, "clip_forward_packed: pooler weights were not loaded");
-  if (head_kind != 0 && head_kind != 1) return fail(CLIP_ERR_ARG, "clip_forward_packed: head_kind");
-  HIP_TRY(hipSetDevice(e->device));
-  hipStream_t st = (hipStream_t)stream;
-  e->last_stream = st;
-  const clip_config& c = e->cfg;
-  const int H = c.hidden_size, I = c.intermediate_size;
-  // the row table is the caller's: a row beyond max_seqlen or a table that does not end at T sets bit 2
-  HIP_TRY(launch_check_rows(cu, n_seqs, T, max_seqlen, e->dev_err, st));
-
-  const bool f32 = e->f32;
-  // Residual operands.  bf16 setting: the GEMM epilogue re-derives the fp32 LayerNorm output from the
-  // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
-  // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
-  // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
-  const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
-  int cur = 0;
-  const float *g_prev = e->embg, *b_prev = e->embb;
-  // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
-  // rewrites); the very first residual is the embedding LayerNorm's row-major copy
-  bool first_res = true;
-  auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
-                     const float* beta) {
-    GemmArgs a{A, W, bias, first_res ? e->xres_rm : e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
-    a.ln_gamma = gamma; a.ln_beta = beta;
-    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err,
-                        e->test_drop ? 1u : 0u};
-    first_res = false;
-    return launch_gemm(a, st);
-  };
-  auto res_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* pre_in,
-                      const float* stats_in, float* pre_out, const int32_t* index) {
-    GemmArgs a{A, W, bias, f32 ? e->x : (const void*)pre_in, pre_out, M, H, K, K, K, H, H,
-               f32 ? EPI_BIAS_RES : EPI_BIAS_LNRES, true, 0, f32};
-    if (!f32) { a.ln_stats = stats_in; a.ln_gamma = g_prev; a.ln_beta = b_prev; a.res_index = index; }
-    return launch_gemm(a, st);
-  };
-  {
-    ProfScope ps(e, CLIP_KIND_EMBED_LN, st);
-    HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
-                            c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
-                            c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
-                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres_rm : nullptr));
-  }
-  GemmArgs g;
-  // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
-  const int Tg = f32 ? T : (T + 255) / 256 * 256;
-  // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
-  // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
-  const bool trim = e->trim_last && c.max_position <= 512 && !f32;
-  for (int i = 0; i < c.num_layers; ++i) {
-    const LayerW& L = e->layers[i];
-    if (trim && i == c.num_layers - 1) {
-      // The rest of the last layer runs on n_seqs rows: only the pooled token's q is ever read, so the
-      // all-token GEMM stops at K and V (the k|v rows of the fused weight, the k|v columns of qkv) and q
-      // is projected for the gathered focus rows alone (same bits: a row's result does not depend on the
-      // GEMM kernel that computes it).
-      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
-      g = GemmArgs{e->x, static_cast<bf16_t*>(L.wqkv) + (size_t)H * H, L.bqkv + H, nullptr,
-                   static_cast<bf16_t*>(e->qkv) + H, Tg, 2 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
-      HIP_TRY(launch_gemm(g, st));
-      HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
-      g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
-      HIP_TRY(launch_gemm(g, st));
-      break;
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
-      g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, f32, 0, f32};
-      HIP_TRY(launch_gemm(g, st));
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_ATTENTION, st);
-      if (f32)
-        HIP_TRY(launch_attention_f32(static_cast<const float*>(e->qkv), cu, static_cast<float*>(e->ctx),
-                                     n_seqs, max_seqlen, c.num_heads, H, st));
-      else
-        HIP_TRY(launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
-                                 n_seqs, max_seqlen, c.num_heads, H, st));
-    }
-    if (fused) {
-      ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b));
-    } else {
-      {
-        ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-        HIP_TRY(res_gemm(e->ctx, L.wo, L.bo, Tg, H, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
-      }
-      cur ^= 1;
-      {
-        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->pre[cur], L.ln1g, L.ln1b, c.layer_norm_eps, e->x, T, H, st, f32,
-                                 f32 ? nullptr : e->stats[cur]));
-      }
-    }
-    g_prev = L.ln1g; b_prev = L.ln1b;
-    {
-      ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
-      g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
-      HIP_TRY(launch_gemm(g, st));
-    }
-    if (fused) {
-      ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b));
-    } else {
-      {
-        ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-        HIP_TRY(res_gemm(e->mid, L.wo2, L.bo2, Tg, I, e->pre[cur], e->stats[cur], e->pre[cur ^ 1], nullptr));
-      }
-      cur ^= 1;
-      {
-        ProfScope ps(e, CLIP_KIND_LAYERNORM, st);
-        HIP_TRY(launch_layernorm(e->pre[cur], L.ln2g, L.ln2b, c.layer_norm_eps, e->x, T, H, st, f32,
-                                 f32 ? nullptr : e->stats[cur]));
-      }
-    }
-    g_prev = L.ln2g; b_prev = L.ln2b;
-  }
-  if (trim) {
-    // ref: sentclf/bert_model.py:52-58 / :234 consume ONE hidden row per sentence, so past the last
-    // layer's K/V projection only that row is computed (SURVEY.md a9): M = n_seqs instead of T.
-    const LayerW& L = e->layers[c.num_layers - 1];
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_attention_focus(static_cast<const bf16_t*>(e->qkv), cu, focus,
-                                     static_cast<bf16_t*>(e->ctx_rows), n_seqs, c.num_heads, H, st,
-                                     static_cast<const bf16_t*>(e->q_rows)));
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
-      if (fused) {
-        // (a one-layer model trims its only layer: the residual is still the embedding's row-major copy)
-        GemmArgs a{e->ctx_rows, L.wo, L.bo, first_res ? e->xres_rm : e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H,
-                   EPI_BIAS_RES16, true};
-        a.res_index = focus;
-        a.res_tiles_n = first_res ? 0 : H / 256;
-        HIP_TRY(launch_gemm(a, st));
-      } else {
-        HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
-      }
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_layernorm(e->pre_rows[0], L.ln1g, L.ln1b, c.layer_norm_eps, e->rows, n_seqs, H, st,
-                               false, e->stats_rows[0]));
-    }
-    g_prev = L.ln1g; b_prev = L.ln1b;
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      g = GemmArgs{e->rows, L.wi, L.bi, nullptr, e->mid_rows, n_seqs, I, H, H, H, I, 0, EPI_BIAS_GELU, false};
-      HIP_TRY(launch_gemm(g, st));
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(res_gemm(e->mid_rows, L.wo2, L.bo2, n_seqs, I, e->pre_rows[0], e->stats_rows[0], e->pre_rows[1], nullptr));
-    }
-    {
-      ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
-      HIP_TRY(launch_layernorm(e->pre_rows[1], L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
-    }
-  }
-  ProfScope ps_head(e, CLIP_KIND_HEAD, st);
-  if (trim) {
-    if (head_kind == 0) {
-      HIP_TRY(launch_classifier(e->rows, nullptr, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
-    } else {
-      g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
-                   EPI_BIAS_TANH, false};
-      HIP_TRY(launch_gemm(g, st));
-      HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
-                                c.num_labels, st));
-    }
-  } else if (head_kind == 0) {
-    HIP_TRY(launch_classifier(e->x, focus, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st, f32));
-  } else {
-    HIP_TRY(launch_gather_rows(e->x, focus, e->rows, n_seqs, H, st, f32));
-    g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
-                 EPI_BIAS_TANH, f32, 0, f32};
-    HIP_TRY(launch_gemm(g, st));
-    HIP_TRY(launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
-                              c.num_labels, st, f32));
-  }
-  // a void call (device error word set) must not look like scores: NaN logits, poll or no poll
-  HIP_TRY(launch_poison_logits(e->dev_err, logits, n_seqs * c.num_labels, st));
-  return CLIP_OK;
+  if (e && e->f16)
+    return forward_packed_impl<k_f16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
+  return forward_packed_impl<k_bf16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
 }
 
 int clip_set_fused_layernorm(clip_engine* e, int32_t on) {
@@ -666,7 +699,17 @@ int clip_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, cons
                    void* stream) {
   GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, out_f32 != 0, tile};
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
-  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_gemm_f16(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res,
+                  void* out, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                  int32_t ldo, int32_t ldres, int32_t epi, int32_t out_f32, int32_t tile,
+                  void* stream) {
+  GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, out_f32 != 0, tile};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  HIP_TRY(k_f16::launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }
 
@@ -680,7 +723,7 @@ int clip_gemm_bf16_lnres(const uint16_t* A, const uint16_t* W, const float* bias
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   if (res_index && (tile == 1 || tile == 2)) return fail(CLIP_ERR_ARG, "gemm: res_index needs a one-tile kernel");
   if (tile == 1) return fail(CLIP_ERR_ARG, "gemm: the LayerNorm-residual epilogue is not built for tile 1");
-  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }
 
@@ -695,7 +738,7 @@ int clip_gemm_bf16_lnout(const uint16_t* A, const uint16_t* W, const float* bias
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   if (!res16 || !xres_out || !part || !flags || !err || N / 256 > 8)
     return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout: null buffer, or more than 8 column tiles");
-  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }
 
@@ -738,7 +781,7 @@ int clip_gemm_bf16_lnout_noalloc(const uint16_t* A, const uint16_t* W, const flo
   }
   g.lnout = LnOutArgs{xres_out, res_tiled != 0, reinterpret_cast<float*>(base),
                       reinterpret_cast<uint32_t*>(base + SCRATCH_FLAGS_OFF), epoch, eps, err, 0};
-  HIP_TRY(launch_gemm(g, st));
+  HIP_TRY(k_bf16::launch_gemm(g, st));
   return CLIP_OK;
 }
 
@@ -747,21 +790,28 @@ int clip_gemm_f32(const float* A, const float* W, const float* bias, const float
                   int32_t ldres, int32_t epi, void* stream) {
   GemmArgs g{A, W, bias, res, out, M, N, K, lda, ldw, ldo, ldres, epi, true, 0, true};
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
-  HIP_TRY(launch_gemm(g, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }
 
 int clip_attention_varlen(const uint16_t* qkv, const int32_t* cu, uint16_t* ctx, int32_t n_seqs,
                           int32_t max_seqlen, int32_t n_heads, int32_t hidden, void* stream) {
   if (!qkv || !cu || !ctx || n_seqs < 0) return fail(CLIP_ERR_ARG, "clip_attention_varlen: bad argument");
-  HIP_TRY(launch_attention(qkv, cu, ctx, n_seqs, max_seqlen, n_heads, hidden, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_attention(qkv, cu, ctx, n_seqs, max_seqlen, n_heads, hidden, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_attention_varlen_f16(const uint16_t* qkv, const int32_t* cu, uint16_t* ctx, int32_t n_seqs,
+                              int32_t max_seqlen, int32_t n_heads, int32_t hidden, void* stream) {
+  if (!qkv || !cu || !ctx || n_seqs < 0) return fail(CLIP_ERR_ARG, "clip_attention_varlen_f16: bad argument");
+  HIP_TRY(k_f16::launch_attention(qkv, cu, ctx, n_seqs, max_seqlen, n_heads, hidden, (hipStream_t)stream));
   return CLIP_OK;
 }
 
 int clip_layernorm(const float* x, const float* gamma, const float* beta, float eps, uint16_t* out,
                    int32_t T, int32_t H, void* stream) {
   if (!x || !gamma || !beta || !out || T < 0) return fail(CLIP_ERR_ARG, "clip_layernorm: bad argument");
-  HIP_TRY(launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream));
+  HIP_TRY(k_bf16::launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream));
   return CLIP_OK;
 }
 
@@ -769,7 +819,7 @@ int clip_layernorm_stats(const float* x, const float* gamma, const float* beta, 
                          uint16_t* out, float* stats, int32_t T, int32_t H, void* stream) {
   if (!x || !gamma || !beta || !out || !stats || T < 0)
     return fail(CLIP_ERR_ARG, "clip_layernorm_stats: bad argument");
-  HIP_TRY(launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream, false, stats));
+  HIP_TRY(k_bf16::launch_layernorm(x, gamma, beta, eps, out, T, H, (hipStream_t)stream, false, stats));
   return CLIP_OK;
 }
 
@@ -779,7 +829,7 @@ int clip_embed_layernorm(const int32_t* ids, const int32_t* type_ids, const int3
                          int32_t vocab, int32_t max_pos, int32_t type_vocab, void* stream) {
   if (!ids || !pos_ids || !word || !pos || !type || !gamma || !beta || !out || T < 0)
     return fail(CLIP_ERR_ARG, "clip_embed_layernorm: bad argument");
-  HIP_TRY(launch_embed_ln(ids, type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H,
+  HIP_TRY(k_bf16::launch_embed_ln(ids, type_ids, pos_ids, word, pos, type, gamma, beta, eps, out, T, H,
                           vocab, max_pos, type_vocab, (hipStream_t)stream));
   return CLIP_OK;
 }

@@ -110,16 +110,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     if constexpr (!F32IN) {
       // all 2 x (TN + TM) fragment reads of the tile are issued up front; the compiler's counted
       // lgkmcnt waits let the first MFMAs start while the later reads are still in flight
-      bf16x8_t af[2][TM], wf[2][TN];
+      opx8_t af[2][TM], wf[2][TN];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int coff = ((ks * 4 + fq) ^ lsw) * 16;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-          wf[ks][i] = *reinterpret_cast<const bf16x8_t*>(base + w_off + i * 16 * 128 + coff);
+          wf[ks][i] = *reinterpret_cast<const opx8_t*>(base + w_off + i * 16 * 128 + coff);
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          af[ks][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off + j * 16 * 128 + coff);
+          af[ks][j] = *reinterpret_cast<const opx8_t*>(base + a_off + j * 16 * 128 + coff);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
             if (GEMM_ABLATE == 1) {
               asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][j]));
             } else {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = MFMA_16x16x32(wf[ks][i], af[ks][j], acc[i][j]);
             }
     } else {
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
         const int row = j * 16 + fr, slot = (i * 4 + fq) ^ ((row & 7) << 1);
         if (GEMM_ABLATE == 3) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3)); continue; }
         *reinterpret_cast<uint2*>(ep + row * 128 + slot * 8) =
-            make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            make_uint2(pack_op2(v0, v1), pack_op2(v2, v3));
       }
 #pragma unroll
     for (int p = 0; p < TM * 2; ++p) {
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
           uint32_t o[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            o[k] = pack_bf16x2(__uint_as_float(vi[k] << 16) + __uint_as_float(ri[k] << 16),
-                               __uint_as_float(vi[k] & 0xffff0000u) + __uint_as_float(ri[k] & 0xffff0000u));
+            o[k] = pack_op2(op2_lo(vi[k]) + op2_lo(ri[k]),
+                               op2_hi(vi[k]) + op2_hi(ri[k]));
           v = make_uint4(o[0], o[1], o[2], o[3]);
         }
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldo + n) = v;
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
               v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             } else {
               const uint2 rv = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n);
-              v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
-              v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+              v.x += op2_lo(rv.x); v.y += op2_hi(rv.x);
+              v.z += op2_lo(rv.y); v.w += op2_hi(rv.y);
             }
           }
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n) = v;
@@ -298,6 +298,7 @@ hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+#if !CLIP_OPERAND_F16
 bool gemm_persist_ok(const GemmArgs& g) {  // shapes the ping-pong persistent kernel (gemm8.hip) takes
   return !g.f32_in && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.M > 0 && g.N > 0 && g.K > 0;
 }
@@ -321,7 +322,10 @@ const char* gemm_check(const GemmArgs& g) {
   return nullptr;
 }
 
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+#endif
+
+hipError_t KSET::launch_gemm(const GemmArgs& g, hipStream_t st) {
+#if !CLIP_OPERAND_F16
   if (g.f32_in) {  // fp32 check mode: 128x128 tile of the same kernel, fp32 operands
     if (!g.out_f32) return hipErrorInvalidValue;
     switch (g.epi) {
@@ -332,6 +336,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
   }
+#else
+  if (g.f32_in) return hipErrorInvalidValue;  // the fp32 check mode lives in the bf16 set
+#endif
   if (g.res_index && g.tile == 2) return hipErrorInvalidValue;
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
                       !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index && g.epi != EPI_BIAS_RES16))

@@ -197,25 +197,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     if (wr == 1) __builtin_amdgcn_s_barrier();  // waves 4..7 run one barrier behind
     LN_STAMP(0)
 
-    bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+    opx8_t af[4][2], bf0[2][2], bf1[2][2];
     for (int kk = 0; kk < nt; kk += 2) {
       auto ktile = [&]<int B>() {
         const char* buf = smem + B * 4 * HT;
         // ---------------- phase A: A0, both B n-halves -> acc[0][*]; stage (t+1).B1, (t+1).A1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          bf0[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c0);
-          bf0[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + i * 2048 + c1);
+          bf0[i][0] = *reinterpret_cast<const opx8_t*>(buf + b_rd + i * 2048 + c0);
+          bf0[i][1] = *reinterpret_cast<const opx8_t*>(buf + b_rd + i * 2048 + c1);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c0);
-          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + a_rd + m * 2048 + c1);
+          af[m][0] = *reinterpret_cast<const opx8_t*>(buf + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const opx8_t*>(buf + a_rd + m * 2048 + c1);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          bf1[i][0] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c0);
-          bf1[i][1] = *reinterpret_cast<const bf16x8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
+          bf1[i][0] = *reinterpret_cast<const opx8_t*>(buf + b_rd + 4096 + i * 2048 + c0);
+          bf1[i][1] = *reinterpret_cast<const opx8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
         }
         if (v1) {
           stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              acc[0][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[0][0][m][i], 0, 0, 0);
-              acc[0][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[0][1][m][i], 0, 0, 0);
+              acc[0][0][m][i] = MFMA_16x16x32(bf0[i][ks], af[m][ks], acc[0][0][m][i]);
+              acc[0][1][m][i] = MFMA_16x16x32(bf1[i][ks], af[m][ks], acc[0][1][m][i]);
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         // ---------------- phase B: A1 -> acc[1][*]; stage (t+2).A0, (t+2).B0; K tile t+1 retired
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          af[m][0] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
-          af[m][1] = *reinterpret_cast<const bf16x8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
+          af[m][0] = *reinterpret_cast<const opx8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
+          af[m][1] = *reinterpret_cast<const opx8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
         }
         if (v2) {
           stage_half(a2, a_off, lda, B * 4 + 0);
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              acc[1][1][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i][ks], af[m][ks], acc[1][1][m][i], 0, 0, 0);
-              acc[1][0][m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i][ks], af[m][ks], acc[1][0][m][i], 0, 0, 0);
+              acc[1][1][m][i] = MFMA_16x16x32(bf1[i][ks], af[m][ks], acc[1][1][m][i]);
+              acc[1][0][m][i] = MFMA_16x16x32(bf0[i][ks], af[m][ks], acc[1][0][m][i]);
             }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               }
               const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
               *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
-                  make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                  make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
             }
             out_store(*reinterpret_cast<const u32x4_t*>(&hv),
                       reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               }
               const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
               *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
-                  make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2f, v3));
+                  make_uint2(pack_op2(v0, v1), pack_op2(v2f, v3));
             }
           const size_t m0 = (size_t)tm * BM + mh * 128 + wr * 64 + m * 16;
 #pragma unroll
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               uint32_t o[4];
 #pragma unroll
               for (int k = 0; k < 4; ++k)
-                o[k] = pack_bf16x2(__uint_as_float(vi[k] << 16) + __uint_as_float(ri[k] << 16),
-                                   __uint_as_float(vi[k] & 0xffff0000u) + __uint_as_float(ri[k] & 0xffff0000u));
+                o[k] = pack_op2(op2_lo(vi[k]) + op2_lo(ri[k]),
+                                   op2_hi(vi[k]) + op2_hi(ri[k]));
               v = make_uint4(o[0], o[1], o[2], o[3]);
             }
             out_store(*reinterpret_cast<u32x4_t*>(&v),
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               float4 v = *reinterpret_cast<const float4*>(scr + row * 128 + ((c16 ^ (row & 7)) * 16));
               if (EPI == EPI_BIAS_RES) {
                 const uint2 rv = *reinterpret_cast<const uint2*>(res + mg * ldres + n);
-                v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
-                v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+                v.x += op2_lo(rv.x); v.y += op2_hi(rv.x);
+                v.z += op2_lo(rv.y); v.w += op2_hi(rv.y);
               } else if (EPI == EPI_BIAS_LNRES) {
                 const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + mg * ldres + n);
                 const float2 sv = ln_stats[mg];
@@ -604,7 +604,7 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st) {
+hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
   if (!gemm_persist_ok(g) || g.res_index) return hipErrorInvalidValue;
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_8<EPI_BIAS, false>(g, st);

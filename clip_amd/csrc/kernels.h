@@ -47,46 +47,15 @@ struct GemmArgs {
   int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles
   LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr, 0};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
 };
+// ---- launchers that do not depend on the 16-bit operand type (defined once, in the bf16 compile)
 const char* gemm_check(const GemmArgs& g);
-hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);
 bool gemm_persist_ok(const GemmArgs& g);
-hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st);  // ping-pong schedule (gemm8.hip), same shapes
-
-// varlen self-attention over packed sequences; qkv [T, 3H] bf16 (q | k | v, heads of 64),
-// q pre-scaled by 1/sqrt(64); ctx [T, H] bf16. One workgroup per (128-row q tile, sequence, head).
-// q_rows (optional, [n_seqs]): attend only from that one token per sequence (focus-only last
-// layer) and write row s of ctx.
-hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
-                            int max_seqlen, int n_heads, int hidden, hipStream_t st);
-
-// fp32 check mode of the same attention: qkv / ctx fp32, fp32 arithmetic throughout
+// fp32 check mode of the attention: qkv / ctx fp32, fp32 arithmetic throughout
 hipError_t launch_attention_f32(const float* qkv, const int32_t* cu_seqlens, float* ctx, int n_seqs,
                                 int max_seqlen, int n_heads, int hidden, hipStream_t st);
-
-// one q row per sequence (token index focus[s]): ctx_rows [n_seqs, H] bf16; sequences up to 512 keys
-hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,
-                                  const int32_t* focus, bf16_t* ctx_rows, int n_seqs, int n_heads,
-                                  int hidden, hipStream_t st,
-                                  const bf16_t* q_rows = nullptr);  // optional dense [n_seqs, hidden] q of the focus tokens
-// out_bf16[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]])
-hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
-                           const float* word, const float* pos, const float* type,
-                           const float* gamma, const float* beta, float eps, void* out, int T,
-                           int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
-                           bool out_f32 = false, float* pre_out = nullptr, float* stats = nullptr,
-                           uint16_t* res16 = nullptr);  // res16: optional fp16 copy of the output
-// out_bf16[t] = LayerNorm(x_f32[t])
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                            void* out, int T, int H, hipStream_t st, bool out_f32 = false,
-                            float* stats = nullptr,      // optional [T] (mean, rstd) pairs out
-                            uint16_t* res16 = nullptr);  // optional fp16 copy of the output
-// dst[i] = src[rows[i]]  (bf16 rows of H)
+// dst[i] = src[rows[i]]  (16-bit rows of H, or fp32)
 hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
                               hipStream_t st, bool f32 = false);
-// logits[i] = Wc . x[rows ? rows[i] : i] + bc     (Wc [L,H] f32, x bf16)
-hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,
-                             const float* bc, float* logits, int n, int H, int L, hipStream_t st,
-                             bool f32 = false);
 // focus[s] = packed token index of the (n_ctx+1)-th sep of sequence s (or of its first token when
 // n_ctx < 0: the [CLS] row); err[0] |= 1 if any sequence does not hold exactly 2*n_ctx+1 seps
 hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
@@ -102,6 +71,44 @@ hipError_t launch_epilogue(const float* logits, const double* label_thresh, floa
 // mean over all elements of BCE-with-logits (ref: bert_model.py:97)
 hipError_t launch_bce_loss(const float* logits, const float* targets, int count, float* loss,
                            hipStream_t st);
+
+// ---- launchers of the kernels that touch 16-bit operands: one set per operand type.  Every kernel
+// file is compiled twice (common.h: CLIP_OPERAND_F16) and defines KSET::launch_* ; the engine picks
+// the set by its precision (k_bf16 also holds the fp32 check-mode instantiations).
+#define CLIP_KERNEL_SET_MEMBERS                                                                      \
+  static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);                                  \
+  static hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st); /* ping-pong schedule */        \
+  /* varlen self-attention over packed sequences; qkv [T, 3H] (q | k | v, heads of 64), q pre-scaled  \
+     by 1/sqrt(64); ctx [T, H].  One workgroup per (128-row q tile, sequence, head). */              \
+  static hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx,      \
+                                     int n_seqs, int max_seqlen, int n_heads, int hidden,            \
+                                     hipStream_t st);                                                \
+  /* one q row per sequence (token index focus[s], or the dense q_rows [n_seqs, hidden]):            \
+     ctx_rows [n_seqs, H]; sequences up to 512 keys */                                               \
+  static hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,             \
+                                           const int32_t* focus, bf16_t* ctx_rows, int n_seqs,       \
+                                           int n_heads, int hidden, hipStream_t st,                  \
+                                           const bf16_t* q_rows = nullptr);                          \
+  /* out[t] = LayerNorm(word[ids[t]] + pos[pos_ids[t]] + type[type_ids[t]]); res16: optional fp16    \
+     copy of the output */                                                                           \
+  static hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids,                     \
+                                    const int32_t* pos_ids, const float* word, const float* pos,     \
+                                    const float* type, const float* gamma, const float* beta,        \
+                                    float eps, void* out, int T, int H, int vocab, int max_pos,      \
+                                    int type_vocab, hipStream_t st, bool out_f32 = false,            \
+                                    float* pre_out = nullptr, float* stats = nullptr,                \
+                                    uint16_t* res16 = nullptr);                                      \
+  /* out[t] = LayerNorm(x_f32[t]); stats: optional [T] (mean, rstd) pairs out */                     \
+  static hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta,          \
+                                     float eps, void* out, int T, int H, hipStream_t st,             \
+                                     bool out_f32 = false, float* stats = nullptr,                   \
+                                     uint16_t* res16 = nullptr);                                     \
+  /* logits[i] = Wc . x[rows ? rows[i] : i] + bc     (Wc [L,H] f32, x 16-bit or fp32) */             \
+  static hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,           \
+                                      const float* bc, float* logits, int n, int H, int L,           \
+                                      hipStream_t st, bool f32 = false);
+struct k_bf16 { CLIP_KERNEL_SET_MEMBERS };
+struct k_f16 { CLIP_KERNEL_SET_MEMBERS };
 // err |= 4 unless cu_seqlens[0] == 0, every row has 1..max_seqlen tokens and cu_seqlens[n] == total_tokens
 hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
                              int32_t* err, hipStream_t st);

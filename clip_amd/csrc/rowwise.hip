@@ -65,9 +65,9 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
 #pragma unroll
       for (int v = 0; v < VEC; ++v) outf[e + v] = y[v];
     } else if (VEC == 4) {
-      *reinterpret_cast<uint2*>(out + e) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+      *reinterpret_cast<uint2*>(out + e) = make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
     } else {
-      *reinterpret_cast<uint32_t*>(out + e) = pack_bf16x2(y[0], y[1]);
+      *reinterpret_cast<uint32_t*>(out + e) = pack_op2(y[0], y[1]);
     }
   }
 }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void classifier_kernel(const void* __restrict_
       x0 = xf.x; x1 = xf.y;
     } else {
       const uint32_t xb = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const bf16_t*>(xv) + r + e);
-      x0 = __uint_as_float(xb << 16); x1 = __uint_as_float(xb & 0xffff0000u);
+      x0 = op2_lo(xb); x1 = op2_hi(xb);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -339,7 +339,7 @@ hipError_t ln_dispatch(int H, bool f32, F&& f) {
 
 }  // namespace
 
-hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+hipError_t KSET::launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
                             void* out, int T, int H, hipStream_t st, bool out_f32, float* stats,
                             uint16_t* res16) {
   if (T <= 0) return hipSuccess;
@@ -350,7 +350,7 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
   });
 }
 
-hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
+hipError_t KSET::launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const int32_t* pos_ids,
                            const float* word, const float* pos, const float* type,
                            const float* gamma, const float* beta, float eps, void* out, int T,
                            int H, int vocab, int max_pos, int type_vocab, hipStream_t st,
@@ -364,6 +364,7 @@ hipError_t launch_embed_ln(const int32_t* ids, const int32_t* type_ids, const in
   });
 }
 
+#if !CLIP_OPERAND_F16
 hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, int n, int H,
                               hipStream_t st, bool f32) {
   if (n <= 0) return hipSuccess;
@@ -373,7 +374,9 @@ hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, i
   return hipGetLastError();
 }
 
-hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,
+#endif
+
+hipError_t KSET::launch_classifier(const void* x, const int32_t* rows, const float* Wc,
                              const float* bc, float* logits, int n, int H, int L, hipStream_t st,
                              bool f32) {
   if (n <= 0) return hipSuccess;
@@ -387,6 +390,7 @@ hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc
   return hipGetLastError();
 }
 
+#if !CLIP_OPERAND_F16
 hipError_t launch_focus_index(const int32_t* ids, const int32_t* cu_seqlens, int n_seqs,
                               int sep_id, int n_ctx, int32_t* focus, int32_t* err,
                               hipStream_t st) {
@@ -435,3 +439,4 @@ hipError_t launch_poison_logits(const int32_t* err, float* logits, int count, hi
   hipLaunchKernelGGL(poison_logits_kernel, dim3((count + 255) / 256), dim3(256), 0, st, err, logits, count);
   return hipGetLastError();
 }
+#endif  // !CLIP_OPERAND_F16

@@ -96,6 +96,8 @@ def main(argv=None):
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--tokens-per-step", type=int, default=131072)
     ap.add_argument("--weights", type=str, default=None, help="state dict (.safetensors); default: procedural")
+    ap.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
+                        help="operand type of the GEMM / attention kernels (clip_set_precision)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start, one per MI355X (ignored under torchrun)")
     ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
     args = ap.parse_args(argv)
@@ -115,6 +117,7 @@ def main(argv=None):
         model.load_state_dict(load_file(args.weights))
     else:
         model.load_state_dict(procedural_state_dict(cfg, 0))
+    model.set_precision(args.precision)
     model.to(device).eval()
     if n_ctx > 0:
         model.set_sep_token_id(102)

@@ -66,3 +66,41 @@ def procedural_state_dict(cfg: BertConfig, seed: int = 0, weight_std: float = 0.
             x = weight_std * x
         out[name] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
     return out
+
+
+def trained_like_state_dict(cfg: BertConfig, seed: int = 0):
+    """Weights with the STATISTICS of a fine-tuned BERT checkpoint, for stress-testing the bf16 budget
+    (no checkpoint is reachable offline; procedural_state_dict is benign: logits within +-1.3, LayerNorm
+    gamma 1 +- 0.1, no outliers).  Same Philox keying, plus:
+      * dense weights N(0, 0.03), embeddings heavy-tailed (Student t, 3 dof, clipped to +-1);
+      * 3 OUTLIER hidden dimensions: every block's output projection writes large values there
+        (rows x4, bias +-1) and every LayerNorm carries gamma x4 and beta +-1 there — the
+        residual-stream outliers of trained transformers;
+      * 6 more LayerNorm gamma entries x5..x10 per LayerNorm;
+      * classifier N(0, 0.045), bias N(0, 1): reference logits span beyond +-6."""
+    sd = procedural_state_dict(cfg, seed, weight_std=0.03)
+    H = cfg.hidden_size
+    g = np.random.Generator(np.random.Philox(key=[seed, 0x74726e64]))
+    outl = g.choice(H, 3, replace=False)
+    sign = g.choice([-1.0, 1.0], 3).astype(np.float32)
+    for name in list(sd):
+        x = sd[name].numpy().copy()
+        gn = np.random.Generator(np.random.Philox(key=[seed + 1, zlib.crc32(name.encode())]))
+        if name.endswith("word_embeddings.weight") or name.endswith("position_embeddings.weight"):
+            x = np.clip(0.03 * gn.standard_t(3, x.shape), -1.0, 1.0).astype(np.float32)
+        elif "LayerNorm.weight" in name:
+            big = gn.choice(H, 6, replace=False)
+            x[big] *= gn.uniform(5.0, 10.0, 6).astype(np.float32)
+            x[outl] = 4.0 * np.abs(x[outl])
+        elif "LayerNorm.bias" in name:
+            x[outl] += 1.0 * sign
+        elif name.endswith("output.dense.weight"):          # attention.output.dense and output.dense
+            x[outl, :] *= 4.0
+        elif name.endswith("output.dense.bias"):
+            x[outl] += 1.0 * sign
+        elif name == "classifier.weight":
+            x = (0.045 * gn.standard_normal(x.shape)).astype(np.float32)
+        elif name == "classifier.bias":
+            x = gn.standard_normal(x.shape).astype(np.float32)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    return sd

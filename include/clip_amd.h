@@ -66,8 +66,15 @@ int clip_finalize_weights(clip_engine* e);
  *   CLIP_PRECISION_FP32: the same kernel templates instantiated on fp32 operands
  *     (v_mfma_f32_16x16x4_f32, fp32 activations end to end; attention in plain fp32 FMAs; every layer
  *     whole, no last-layer trimming) — logits within 1e-4 of the reference.  ~1/16 of the MFMA rate:
- *     a checker for the bf16 path, not a production setting. */
-enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1 };
+ *     a checker for the bf16 path, not a production setting;
+ *   CLIP_PRECISION_F16: the same kernels compiled for fp16 operands (v_mfma_*_f16: the same MFMA rate as
+ *     bf16, 11 significant bits instead of 8, fp32 accumulation / LayerNorm / softmax as in the bf16
+ *     setting).  For checkpoints whose logits reach beyond +-2: operand rounding is ~1/8 of bf16's, so the
+ *     2e-2 budget holds on weights with trained-like statistics (tests/test_gpu_parity_gates.py), where
+ *     bf16 operands cannot (their rounding alone is ~0.5 % of the logit spread).  The price is fp16's
+ *     RANGE: a weight beyond +-65504 is refused at load; an activation beyond it becomes inf and the
+ *     logits NaN (never silently wrong).  BERT-base activations stay far inside it. */
+enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1, CLIP_PRECISION_F16 = 2 };
 int clip_set_precision(clip_engine* e, int32_t precision);
 
 /* Replaces _collect_focus_repr's index search (bert_model.py:52): for each packed sequence the
@@ -121,6 +128,11 @@ int clip_gemm_bf16(const uint16_t* dev_A, const uint16_t* dev_W, const float* de
                    const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
                    int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
                    int32_t out_f32, int32_t tile, void* stream);
+/* clip_gemm_bf16 on fp16 operands (A, W, res fp16; out fp16 or fp32): the k_f16 kernel set */
+int clip_gemm_f16(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                  const uint16_t* dev_res, void* dev_out, int32_t M, int32_t N, int32_t K,
+                  int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, int32_t epi,
+                  int32_t out_f32, int32_t tile, void* stream);
 /* The residual form the engine uses in the bf16 setting: out_f32[m,n] = A W^T + bias + LN(pre)[r,n]
  * with r = res_index ? res_index[m] : m, where LN(pre) is the fp32 LayerNorm output
  * (modeling_bert.py:292,350: what the reference adds as the residual) recomputed in the epilogue from
@@ -177,6 +189,10 @@ int clip_gemm_f32(const float* dev_A, const float* dev_W, const float* dev_bias,
 int clip_attention_varlen(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens,
                           uint16_t* dev_ctx, int32_t n_seqs, int32_t max_seqlen, int32_t n_heads,
                           int32_t hidden, void* stream);
+/* the same on fp16 q/k/v and ctx (k_f16 kernel set) */
+int clip_attention_varlen_f16(const uint16_t* dev_qkv, const int32_t* dev_cu_seqlens,
+                              uint16_t* dev_ctx, int32_t n_seqs, int32_t max_seqlen, int32_t n_heads,
+                              int32_t hidden, void* stream);
 /* out_bf16[t] = LayerNorm(x_f32[t]) (modeling_bert.py:292,350) */
 int clip_layernorm(const float* dev_x, const float* dev_gamma, const float* dev_beta, float eps,
                    uint16_t* dev_out, int32_t T, int32_t H, void* stream);

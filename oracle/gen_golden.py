@@ -106,11 +106,11 @@ def pack(rows):
     return np.concatenate([np.asarray(r, np.int32) for r in rows]), lens
 
 
-def make_case(name, cfg, seed, rows, n_ctx, batch_size=8):
+def make_case(name, cfg, seed, rows, n_ctx, batch_size=8, weights="procedural"):
     import bert_model as ref_model
-    from clip_amd.weights import procedural_state_dict
+    from clip_amd.weights import procedural_state_dict, trained_like_state_dict
     from clip_amd.constants import SEP_ID
-    sd = procedural_state_dict(cfg, seed)
+    sd = trained_like_state_dict(cfg, seed) if weights == "trained_like" else procedural_state_dict(cfg, seed)
     cls = (ref_model.BertSequenceMultilabelClassificationContext if n_ctx > 0
            else ref_model.BertForSequenceMultilabelClassification)
     model = cls(hf_config(cfg))
@@ -127,7 +127,7 @@ def make_case(name, cfg, seed, rows, n_ctx, batch_size=8):
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         cfg=np.asarray([str(asdict(cfg))]), seed=np.int64(seed), n_ctx=np.int64(n_ctx),
-        batch_size=np.int64(batch_size), ids=ids, lens=lens, labels=labels,
+        weights=np.asarray([weights]), batch_size=np.int64(batch_size), ids=ids, lens=lens, labels=labels,
         ref_logits=logits.astype(np.float32), ref_probs=probs.astype(np.float32),
         ref_batch_loss=losses)
     print(name, "done", logits.shape, "logit range", logits.min(), logits.max())
@@ -140,6 +140,13 @@ def main():
     torch.set_num_threads(8)
     from clip_amd.config import BertConfig
     from clip_amd import synth
+    only = sys.argv[1:]          # e.g. `python oracle/gen_golden.py base_ctx_stress`: just these cases
+    global make_case
+    _make = make_case
+
+    def make_case(name, *a, **kw):
+        if not only or name in only:
+            _make(name, *a, **kw)
 
     tiny = BertConfig(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                       intermediate_size=512, max_position_embeddings=512)
@@ -165,6 +172,16 @@ def main():
     make_case("base_ctx", base, 7, rows, 2)
     rows = synth.sentence_rows(48, base.vocab_size, max_len=64, seed=1001)
     make_case("base_sent", base, 8, rows, 0)
+
+    # trained-like statistics (clip_amd.weights.trained_like_state_dict): logits beyond +-6, LayerNorm gamma
+    # outliers, outlier hidden dimensions, heavy-tailed embeddings — the stress case of the bf16 budget
+    rows = synth.context_rows(40, 2, base.vocab_size, max_len=256, seed=31)
+    rows += synth.context_rows(8, 2, base.vocab_size, max_len=256, seed=32, fixed_len=256)
+    rows += synth.context_rows(6, 2, base.vocab_size, max_len=512, seed=33, sigma=1.0, seg_hi=200)
+    rows += synth.context_rows(2, 2, base.vocab_size, max_len=512, seed=34, fixed_len=512)
+    make_case("base_ctx_stress", base, 9, rows, 2, weights="trained_like")
+    rows = synth.sentence_rows(32, base.vocab_size, max_len=64, seed=35)
+    make_case("base_sent_stress", base, 10, rows, 0, weights="trained_like")
 
 
 if __name__ == "__main__":

@@ -24,7 +24,15 @@ def load_golden(name):
     off = np.concatenate(([0], np.cumsum(g["lens"])))
     g["rows"] = [g["ids"][off[i]:off[i + 1]] for i in range(len(g["lens"]))]
     g["seed"], g["n_ctx"], g["batch_size"] = int(g["seed"]), int(g["n_ctx"]), int(g["batch_size"])
+    g["weights"] = str(z["weights"][0]) if "weights" in z.files else "procedural"
     return g
+
+
+def golden_state_dict(g):
+    """The weights a golden case was generated with (oracle/gen_golden.py): seeds travel, tensors do not."""
+    from clip_amd.weights import procedural_state_dict, trained_like_state_dict
+    make = trained_like_state_dict if g["weights"] == "trained_like" else procedural_state_dict
+    return make(g["cfg"], g["seed"])
 
 
 @pytest.fixture(scope="session")

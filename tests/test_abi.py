@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.clip_abi_version() == 1
+    assert lib.clip_abi_version() == 2
 
 
 def test_argument_errors_without_a_device():

@@ -430,3 +430,48 @@ def test_gemm_fused_layernorm_epilogue(lib, M, N, K):
         outs.append((x.clone(), xres.clone()))
     for o in outs[1:]:
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
+@pytest.mark.parametrize("M,N,K,epi,out_f32,tile", [
+    (300, 768, 768, 0, False, 128), (48, 768, 768, 3, False, 0), (66 * 256, 2304, 768, 0, False, 2),
+    (40 * 256, 3072, 768, 1, False, 2), (8 * 256, 768, 3072, 2, True, 2), (520, 3072, 768, 1, False, 256)])
+def test_gemm_f16_operand_set(lib, M, N, K, epi, out_f32, tile):
+    """The k_f16 kernel set (CLIP_PRECISION_F16): the same GEMM kernels compiled for fp16 operands.
+    Against an fp32 reference; the output rounding is fp16's (2^-11 relative), 8x finer than bf16's."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + epi)
+    A = torch.randn(M, K, generator=g).to(torch.float16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.float16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.float16).cuda() if epi == 2 else None
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.float16, device="cuda")
+    _lib.check(lib.clip_gemm_f16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(out), M, N, K, K, K, N,
+                                 0 if res is None else N, epi, int(out_f32), tile, _lib.stream_ptr()))
+    _sync()
+    ref = A.float() @ W.float().T + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = ref + res.float()
+    elif epi == 3:
+        ref = torch.tanh(ref)
+    tol = 2e-3 + (0 if out_f32 else 1e-3 * ref.abs().max().item())
+    if epi == 1 and not out_f32:
+        tol += 1.5e-4                 # the degree-6 GELU polynomial of the 16-bit-output epilogue
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < tol
+
+
+def test_attention_f16_operand_set(lib):
+    heads, H = 12, 768
+    lens = [1, 7, 64, 65, 128, 129, 200, 256, 300, 512]
+    T = sum(lens)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    qkv = (torch.randn(T, 3 * H, generator=g) * 0.7).to(torch.float16).cuda()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    ctx = torch.full((T, H), float("nan"), dtype=torch.float16, device="cuda")
+    _lib.check(lib.clip_attention_varlen_f16(_lib.ptr(qkv), _lib.ptr(cu), _lib.ptr(ctx), len(lens), max(lens), heads, H,
+                                             _lib.stream_ptr()))
+    _sync()
+    ref = _attn_ref(qkv, lens, heads)
+    assert torch.isfinite(ctx.float()).all()
+    assert (ctx.float() - ref).abs().max().item() < 3e-3      # bf16 set: 2e-2 on the same inputs

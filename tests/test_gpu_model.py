@@ -17,7 +17,8 @@ BF16_LOGIT_TOL = 2e-2   # BASELINE.json north_star: per-label logits within 2e-2
 
 def build_model(g):
     model = args_to_model(g["n_ctx"])(g["cfg"], max_tokens=16384, max_seqs=256)
-    model.load_state_dict(procedural_state_dict(g["cfg"], g["seed"]))
+    from conftest import golden_state_dict
+    model.load_state_dict(golden_state_dict(g))
     model.to("cuda").eval()
     if g["n_ctx"] > 0:
         model.set_sep_token_id(102)
