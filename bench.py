@@ -143,6 +143,12 @@ def main():
     if flags.value or int(err.item()):
         raise RuntimeError(f"rank {rank}: engine error word {flags.value}, [SEP]-count word {int(err.item())} "
                            "after the timed loop: results void")
+    # sustained MFMA peak of THIS board (register-only MFMA loop, clip_mfma_peak), measured right after the
+    # timed steps: the nameplate 2.5 PF assumes 2.4 GHz, which no board holds under a dense MFMA stream
+    peak_best, peak_mean, peak_ms = C.c_double(0), C.c_double(0), C.c_double(0)
+    if rank == 0:
+        _lib.check(lib.clip_mfma_peak(_lib.PRECISION_BF16, 12000, 5, C.byref(peak_best), C.byref(peak_mean),
+                                      C.byref(peak_ms)))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,6 +206,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<EPI_BIAS_GELU,bf16> (FFN up, M=%d N=%d K=%d; layers 1-11, the trimmed last layer is timed apart)" % (T, I, H),
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "peak_sustained": round(peak_mean.value, 1),
+                         "frac_sustained": round(achieved / peak_mean.value, 4),
+                         "peak_sustained_note": "clip_mfma_peak: register-only v_mfma_f32_16x16x32_bf16 loop, random operands, "
+                                                "all CUs x 2 waves/SIMD, mean of 5 launches of %.2f ms (best %.1f TF); implied "
+                                                "clock %.2f GHz at 16 cycles per MFMA" % (
+                                                    peak_ms.value, peak_best.value,
+                                                    peak_mean.value * 1e12 / (torch.cuda.get_device_properties(device).multi_processor_count * 4 * 1024.0) / 1e9),
                          "mfma_busy_frac_pmc": mfma_busy,
                          "traffic_note": "HBM-side bytes/launch from PMC passes (profiles/%s); algorithmic operand+output bytes = %d" % (PMC_FILE, 2 * T * H + 2 * I * H + 2 * T * I),
                          "avg_launch_ms": round(avg_ms, 5), "launches": int(cnt[dominant]),

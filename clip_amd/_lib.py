@@ -59,6 +59,7 @@ SIGNATURES = {
     "clip_preferred_step_tokens": [_p, _p],
     "clip_profile_enable": [_p, C.c_uint32],
     "clip_profile_read": [_p, _p, _p, _i32],
+    "clip_mfma_peak": [_i32, _i32, _i32, _p, _p, _p],
     "clip_last_error": [],
     "clip_abi_version": [],
 }

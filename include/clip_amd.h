@@ -247,6 +247,14 @@ enum {
 int clip_profile_enable(clip_engine* e, uint32_t kind_mask);
 int clip_profile_read(clip_engine* e, double* ms_per_kind, int64_t* launches_per_kind, int32_t reset);
 
+/* Sustained MFMA peak of the current device (no counterpart in the reference; SURVEY.md 8d: measure the
+ * peak before quoting a fraction of it): a register-only v_mfma_f32_16x16x32 loop on random operands of
+ * type `operand` (CLIP_PRECISION_BF16 or CLIP_PRECISION_F16), one 8-wave workgroup per CU (2 waves per
+ * SIMD), `iters` x 16 MFMAs per wave (12000 iters ~ 3 ms), launched `repeats` times after one warm-up
+ * launch on the null stream.  Returns the best and the mean TFLOP/s and the mean launch time. */
+int clip_mfma_peak(int32_t operand, int32_t iters, int32_t repeats, double* tflops_best,
+                   double* tflops_mean, double* ms_mean);
+
 /* message of the last failing call on this thread ("" if none) */
 const char* clip_last_error(void);
 /* ABI version of this header */

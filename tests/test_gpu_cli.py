@@ -107,3 +107,43 @@ def test_cli_columnar_round_trip_and_chunking(tmp_path):
     assert outs[0] == outs[1] and len(outs[0][0]) > 0
     with pytest.raises(ValueError):
         apply_bert_unlabeled.main([str(rows_dir), str(model_dir), "w.pth", "--n_context_sentences", "1"])
+
+
+def test_cli_scores_every_row_including_trimmed_and_backfilled(tmp_path):
+    """--threshold -1 keeps every row: one score per input row, in input order, each within 2e-3 of the
+    oracle on the reference-semantics collator tensors — including the rows that went through the trim loop
+    and the back-fill of bert.py:114-145 (focus sentence alone >= 512 tokens)."""
+    cfg = BertConfig(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=512)
+    model_dir = tmp_path / "model"
+    cfg.save_pretrained(str(model_dir))
+    shutil.copyfile(os.path.join(G, "vocab.txt"), model_dir / "vocab.txt")
+    sd = procedural_state_dict(cfg, 33)
+    run_dir = tmp_path / "run"
+    run_dir.mkdir()
+    torch.save(sd, run_dir / "w.pth")
+    path = os.path.join(G, "notes_synth.csv")
+    apply_bert_unlabeled.main([path, str(model_dir), str(run_dir / "w.pth"), "--n_context_sentences", "2",
+                               "--threshold", "-1", "--tokens_per_step", "4096"])
+    got = [(int(r[0]), int(r[1]), np.float32(r[2])) for r in csv.reader(open(run_dir / "ttp_doc_sents.csv"))]
+    tok = BertWordPieceTokenizer(os.path.join(G, "vocab.txt"))
+    ds = datasets.SentEvalDataset(path, "multilabel", n_context_sentences=2)
+    assert len(got) == len(ds)
+    n_long = n_backfilled = 0
+    k = 0
+    with torch.no_grad():
+        for i in range(0, len(ds), 8):
+            items = [ds[j] for j in range(i, min(i + 8, len(ds)))]
+            x = collate.ctx_collator(items, "multilabel", tok)
+            for it in items:
+                s, rep = collate._fit_context(" ".join(it[0]).lower(), tuple(c.lower() for c in it[5]), tok)
+                n_backfilled += rep is not None
+            n_long += int((x["attention_mask"].sum(1) >= 511).sum())
+            _, logits = O.context_forward(sd, cfg, x["input_ids"], x["attention_mask"], x["token_type_ids"],
+                                          x["labels"], tok.sep_token_id, 2)
+            _, _, score = O.score_epilogue(logits, -1.0)
+            for j in range(len(items)):
+                assert got[k][:2] == (int(x["doc_ids"][j]), int(x["sent_ixs"][j]))
+                assert abs(float(got[k][2]) - float(score[j])) < 2e-3, (k, got[k], score[j])
+                k += 1
+    assert n_long >= 1 and n_backfilled >= 1      # the fixture does exercise those branches
