@@ -43,8 +43,9 @@ def test_fit_label_thresholds_through_the_engine(tmp_path, precision):
 
     metrics_cpu, thr_cpu, _ = LT.balance_each_label(p_ref, y)
     thr_cpu = np.asarray(thr_cpu, np.float64)
-    # thresholds equal, except where the oracle's own F1 at the two candidates is within 1e-3 (a plateau
-    # of the sweep: which of two equally good thresholds wins may flip with a 1e-3 change of one score)
+    # thresholds equal, except where the oracle's own F1 at the two candidates is within 1e-3 (f16; bf16,
+    # whose probabilities move by up to 1e-2 with this x6 classifier: 3e-3 = 2 of 1500 rows changing side) —
+    # a plateau of the sweep, where which of two equally good thresholds wins flips with one score
     for j, label in enumerate(LABEL_TYPES):
         if thr_gpu[j] != thr_cpu[j]:
             f1 = LT.threshold_metrics(p_ref[:, j], y[:, j], thresholds=np.array([thr_gpu[j], thr_cpu[j]]))["f1"]
