@@ -40,6 +40,8 @@ SIGNATURES = {
     "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
+    "clip_mlm_head": [_p, _p, _p, _i32, _p, _p, _i32, _p],
+    "clip_ce_loss": [_p, _p, _i32, _i32, _p, _p, _i32, _p],
     "clip_gemm_bf16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f16": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_bf16_lnres": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],

@@ -50,6 +50,7 @@ def pack_padded(input_ids, attention_mask=None, token_type_ids=None, position_id
 class _EngineModel:
     """Shared plumbing: config, weights, engine lifetime, packed forward."""
     head_kind = 0
+    mlm_head = False
 
     def __init__(self, config: BertConfig, max_tokens=65536, max_seqs=16384):
         config.validate_for_device()
@@ -99,12 +100,15 @@ class _EngineModel:
                   os.path.join(path, "model.safetensors"))
 
     def load_state_dict(self, sd, strict=True):
-        shapes = state_dict_shapes(self.config)
+        shapes = state_dict_shapes(self.config, self.mlm_head)
         sd = {k: v for k, v in sd.items() if k not in _IGNORED_KEYS}
         missing = [k for k in shapes if k not in sd]
         unexpected = [k for k in sd if k not in shapes]
         if self.head_kind == 0:  # the context head never reads the pooler
             missing = [k for k in missing if not k.startswith("bert.pooler.")]
+        if any(k in sd for k in ("mlm_predictions.bias", "mlm_predictions.decoder.bias")):
+            # one output bias: tied `mlm_predictions.bias` in old checkpoints, `decoder.bias` in new ones
+            missing = [k for k in missing if k not in ("mlm_predictions.bias", "mlm_predictions.decoder.bias")]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
         for k, v in sd.items():
@@ -274,6 +278,80 @@ class BertSequenceMultilabelClassificationContext(_EngineModel):
         if self.sep_token_id is None or self.n_context_sentences is None:
             raise AttributeError("call set_sep_token_id() and set_n_context_sentences() first")
         return self._focus(ids, cu_seqlens, self.n_context_sentences, self.sep_token_id, check)
+
+
+class BertContextMLMSwitch(BertSequenceMultilabelClassificationContext):
+    """ref: sentclf/bert_model.py:106-186 — the BERT+Context encoder with an LM prediction head on every
+    token and the switch classifier (2 classes) on the focus [SEP] row, as task-targeted pre-training
+    evaluates it.  INFERENCE forward only (no autograd here): (total_loss, logits) as the reference returns
+    them, total_loss = CrossEntropy(mlm_scores, mlm_labels) + CrossEntropy(logits, labels).
+    CrossEntropyLoss ignores label -100, so the 768 -> vocab decoder runs on the labelled positions only
+    (clip_mlm_head); `mlm_scores_at` gives the scores of bert_model.py:165 at those positions."""
+    mlm_head = True
+
+    def _ensure_engine(self):
+        h = super()._ensure_engine()
+        if not getattr(self, "_trim_off", None) == h.value:
+            _lib.check(_lib.load().clip_set_trim_last_layer(h, 0))     # the LM head reads every token's last hidden state
+            self._trim_off = h.value
+        return h
+
+    def expand_vocab_by_num(self, num):
+        """ref: bert_model.py:116-135 — `num` more word embeddings (unit-norm random rows), a fresh
+        decoder of the new size with zero bias; config.vocab_size grows."""
+        sd = self.state_dict()
+        H = self.config.hidden_size
+        init = torch.nn.Embedding(num, H).weight.data.clone()
+        init = init / init.norm(dim=1).unsqueeze(dim=1)
+        sd["bert.embeddings.word_embeddings.weight"] = torch.cat([sd["bert.embeddings.word_embeddings.weight"], init])
+        self.config.vocab_size += num
+        dec = torch.nn.Linear(H, self.config.vocab_size, bias=False)
+        sd["mlm_predictions.decoder.weight"] = dec.weight.data.clone()
+        sd["mlm_predictions.bias"] = torch.zeros(self.config.vocab_size)
+        sd["mlm_predictions.decoder.bias"] = torch.zeros(self.config.vocab_size)
+        self.load_state_dict(sd)
+
+    def _mlm_rows(self, mlm_labels, attention_mask):
+        """packed token indices and labels of the positions CrossEntropyLoss does not ignore"""
+        B, S = mlm_labels.shape
+        mask = torch.ones((B, S), dtype=torch.bool, device=mlm_labels.device) if attention_mask is None \
+            else attention_mask.to(torch.bool)
+        packed_index = (torch.cumsum(mask.reshape(-1).to(torch.int64), 0) - 1).reshape(B, S)
+        sel = mlm_labels != -100
+        if bool((sel & ~mask).any()):
+            raise NotImplementedError("an MLM label on a masked-out (padding) position: its hidden state is not "
+                                      "computed by the packed engine")
+        return packed_index[sel].to(torch.int32).contiguous(), mlm_labels[sel].to(torch.int32).contiguous()
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, labels=None, mlm_labels=None, output_attentions=None,
+                output_hidden_states=None, doc_positions=None, return_mlm_scores=False):
+        out = super().forward(input_ids=input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                              position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
+                              output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                              doc_positions=doc_positions)
+        logits = out[0]
+        outputs = (logits,) if labels is not None else ((),)       # bert_model.py:167-172
+        scores = None
+        if mlm_labels is not None:
+            lib, h = _lib.load(), self._ensure_engine()
+            rows, labs = self._mlm_rows(mlm_labels.to(self.device), attention_mask)
+            n = rows.numel()
+            loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            if return_mlm_scores:
+                scores = torch.empty((n, self.config.vocab_size), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.clip_mlm_head(h, _lib.ptr(rows), _lib.ptr(labs), n, _lib.ptr(scores), _lib.ptr(loss), 0,
+                                             _lib.stream_ptr()))
+                if labels is not None:                              # + switch loss (bert_model.py:180-183)
+                    lab = labels.to(self.device).reshape(-1).to(torch.int32).contiguous()
+                    row_loss = torch.empty(lab.numel(), dtype=torch.float32, device=self.device)
+                    _lib.check(lib.clip_ce_loss(_lib.ptr(logits), _lib.ptr(lab), lab.numel(), self.num_labels,
+                                                _lib.ptr(row_loss), _lib.ptr(loss), 1, _lib.stream_ptr()))
+            outputs = (loss[0],) + outputs
+        return outputs + ((scores,) if return_mlm_scores else ())
+
+    __call__ = forward
 
 
 class BertForSequenceMultilabelClassification(_EngineModel):

@@ -1,5 +1,6 @@
 // C ABI of libclip_amd.so (include/clip_amd.h): engine object = device weights + activation
 // workspace; clip_forward_packed chains the kernels of one BERT(+Context) forward on one stream.
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -81,6 +82,15 @@ struct clip_engine {
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
   uint32_t epoch = 0;
+  // LM prediction head of BertContextMLMSwitch (bert_model.py:113,165; optional weights mlm_predictions.*)
+  void *w_mlm_t = nullptr, *w_mlm_dec = nullptr;  // transform dense [H,H]; decoder [vocab_pad,H] (zero rows past vocab)
+  float *b_mlm_t = nullptr, *g_mlm = nullptr, *be_mlm = nullptr, *b_mlm_dec = nullptr;  // decoder bias: -1e30 past vocab
+  int vocab_pad = 0, mlm_vocab = 0;
+  bool last_full = false;  // the latest forward left every token's last hidden state in x (no last-layer trimming)
+  int last_tokens = 0;
+  void *mlm_rows = nullptr, *mlm_t = nullptr;  // [cap, H] gathered hidden rows / transformed rows
+  float *mlm_pre = nullptr, *mlm_scores = nullptr, *mlm_row_loss = nullptr;
+  int mlm_cap = 0;
   hipStream_t last_stream = nullptr;  // stream of the latest forward: clip_poll_errors reads behind it
   bool test_drop = false;             // CLIP_AMD_TEST_DROP_PUBLISH=1 (tests): one fused-LayerNorm tile never publishes
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
@@ -441,8 +451,60 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(KS::launch_classifier(e->pooled, nullptr, e->wcls, e->bcls, logits, n_seqs, H,
                               c.num_labels, st, f32));
   }
+  e->last_full = !trim;
+  e->last_tokens = T;
   // a void call (device error word set) must not look like scores: NaN logits, poll or no poll
   HIP_TRY(launch_poison_logits(e->dev_err, logits, n_seqs * c.num_labels, st));
+  return CLIP_OK;
+}
+
+// The LM head + CrossEntropyLoss of BertContextMLMSwitch.forward (bert_model.py:165,175-179) on the rows
+// that carry an MLM label: CrossEntropyLoss ignores label -100, so the 768 -> vocab decoder runs on those
+// rows only (the reference computes all B*S rows of scores and discards ~95 % of them).
+template <class KS>
+int mlm_head_impl(clip_engine* e, const int32_t* rows, const int32_t* labels, int32_t n, float* scores_out,
+                  float* loss, int32_t accumulate, void* stream) {
+  if (!e || !loss || (n > 0 && (!rows || !labels)) || n < 0) return fail(CLIP_ERR_ARG, "clip_mlm_head: bad argument");
+  if (!e->finalized || !e->w_mlm_dec) return fail(CLIP_ERR_STATE, "clip_mlm_head: no mlm_predictions weights were loaded");
+  if (!e->last_full)
+    return fail(CLIP_ERR_STATE, "clip_mlm_head: the latest forward trimmed its last layer (clip_set_trim_last_layer(e, 0) first)");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  const clip_config& c = e->cfg;
+  const int H = c.hidden_size, V = e->mlm_vocab, Vp = e->vocab_pad;
+  const bool f32 = e->f32;
+  const size_t es = f32 ? 4 : 2;
+  if (n > e->mlm_cap) {  // grow-only workspace of the head (rows x padded vocabulary of fp32 scores)
+    HIP_TRY(hipStreamSynchronize(st));
+    const int cap = (n + 255) / 256 * 256;
+    for (void* p : {e->mlm_rows, e->mlm_t, (void*)e->mlm_pre, (void*)e->mlm_scores, (void*)e->mlm_row_loss})
+      if (p) { (void)hipFree(p); e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), p)); }
+    e->mlm_rows = e->mlm_t = nullptr; e->mlm_pre = e->mlm_scores = e->mlm_row_loss = nullptr; e->mlm_cap = 0;
+    int rc = 0;
+    rc = rc ? rc : dev_alloc(e, &e->mlm_rows, (size_t)cap * H * es);
+    rc = rc ? rc : dev_alloc(e, &e->mlm_t, (size_t)cap * H * es);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->mlm_pre, (size_t)cap * H * 4);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->mlm_scores, (size_t)cap * Vp * 4);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->mlm_row_loss, (size_t)cap * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(e->mlm_rows, 0, (size_t)cap * H * es));
+    HIP_TRY(hipMemset(e->mlm_t, 0, (size_t)cap * H * es));
+    e->mlm_cap = cap;
+  }
+  if (n > 0) {
+    HIP_TRY(launch_gather_rows(e->x, rows, e->mlm_rows, n, H, st, f32));
+    // transform: dense + erf-GELU (fp32 out, exact form) -> LayerNorm -> operand rows
+    GemmArgs g{e->mlm_rows, e->w_mlm_t, e->b_mlm_t, nullptr, e->mlm_pre, n, H, H, H, H, H, 0, EPI_BIAS_GELU, true, 0, f32};
+    HIP_TRY(KS::launch_gemm(g, st));
+    HIP_TRY(KS::launch_layernorm(e->mlm_pre, e->g_mlm, e->be_mlm, c.layer_norm_eps, e->mlm_t, n, H, st, f32));
+    // decoder: [n, H] x [Vp, H]^T + bias -> fp32 scores (columns past V: -1e30).  Whole 256-row tiles when
+    // they are there (the workspace is padded and zeroed), so the ping-pong kernel takes the big calls.
+    const int Mg = (!f32 && n >= 4096) ? (n + 255) / 256 * 256 : n;
+    g = GemmArgs{e->mlm_t, e->w_mlm_dec, e->b_mlm_dec, nullptr, e->mlm_scores, Mg, Vp, H, H, H, Vp, 0, EPI_BIAS, true, 0, f32};
+    HIP_TRY(KS::launch_gemm(g, st));
+    HIP_TRY(launch_ce_rows(e->mlm_scores, Vp, V, labels, n, e->mlm_row_loss, scores_out, st));
+  }
+  HIP_TRY(launch_mean_loss(e->mlm_row_loss, n, loss, accumulate, st));
   return CLIP_OK;
 }
 
@@ -499,7 +561,8 @@ int clip_load_weight(clip_engine* e, const char* name, const float* host_data, i
   if (e->finalized) return fail(CLIP_ERR_STATE, "clip_load_weight: weights already finalized");
   const std::string k(name);
   const bool known = k.rfind("bert.embeddings.", 0) == 0 || k.rfind("bert.encoder.layer.", 0) == 0 ||
-                     k.rfind("bert.pooler.dense.", 0) == 0 || k.rfind("classifier.", 0) == 0;
+                     k.rfind("bert.pooler.dense.", 0) == 0 || k.rfind("classifier.", 0) == 0 ||
+                     k.rfind("mlm_predictions.", 0) == 0;
   if (!known || k == "bert.embeddings.position_ids" || k == "bert.embeddings.token_type_ids")
     return fail(CLIP_ERR_ARG, "clip_load_weight: '%s' is not a parameter of this model", name);
   e->host_w[k].assign(host_data, host_data + numel);
@@ -582,6 +645,34 @@ int clip_finalize_weights(clip_engine* e) {
         return rc;
     }
   }
+  {
+    // optional LM head (BertLMPredictionHead: transform dense + GELU + LayerNorm, decoder H -> vocab + bias).
+    // decoder.bias is the tied `mlm_predictions.bias` in old checkpoints, its own tensor in new ones.
+    auto wt = e->host_w.find("mlm_predictions.transform.dense.weight");
+    auto wd = e->host_w.find("mlm_predictions.decoder.weight");
+    if (wt != e->host_w.end() && wd != e->host_w.end()) {
+      GET(bt, "mlm_predictions.transform.dense.bias", H);
+      GET(lg, "mlm_predictions.transform.LayerNorm.weight", H);
+      GET(lb, "mlm_predictions.transform.LayerNorm.bias", H);
+      auto bd = e->host_w.find("mlm_predictions.decoder.bias");
+      if (bd == e->host_w.end()) bd = e->host_w.find("mlm_predictions.bias");
+      const size_t V = wd->second.size() / H;
+      if (wt->second.size() != H * H || wd->second.size() != V * H || V < 2 || bd == e->host_w.end() ||
+          bd->second.size() != V)
+        return fail(CLIP_ERR_ARG, "mlm_predictions weights have inconsistent sizes");
+      // pad the vocabulary to whole 256-column tiles: zero weight rows, bias -1e30 (vanishes in logsumexp)
+      const size_t Vp = (V + 255) / 256 * 256;
+      std::vector<float> wpad(Vp * H, 0.f), bpad(Vp, -1e30f);
+      memcpy(wpad.data(), wd->second.data(), V * H * 4);
+      memcpy(bpad.data(), bd->second.data(), V * 4);
+      e->vocab_pad = (int)Vp;
+      if ((rc = upload_w(e, wt->second.data(), H * H, &e->w_mlm_t)) || (rc = upload_f32(e, *bt, &e->b_mlm_t)) ||
+          (rc = upload_f32(e, *lg, &e->g_mlm)) || (rc = upload_f32(e, *lb, &e->be_mlm)) ||
+          (rc = upload_w(e, wpad.data(), Vp * H, &e->w_mlm_dec)) || (rc = upload_f32(e, bpad, &e->b_mlm_dec)))
+        return rc;
+      e->mlm_vocab = (int)V;
+    }
+  }
 #undef GET
   e->host_w.clear();
   e->finalized = true;
@@ -612,6 +703,21 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   if (e && e->f16)
     return forward_packed_impl<k_f16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
   return forward_packed_impl<k_bf16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
+}
+
+int clip_mlm_head(clip_engine* e, const int32_t* rows, const int32_t* labels, int32_t n, float* scores_out,
+                  float* loss, int32_t accumulate, void* stream) {
+  if (e && e->f16) return mlm_head_impl<k_f16>(e, rows, labels, n, scores_out, loss, accumulate, stream);
+  return mlm_head_impl<k_bf16>(e, rows, labels, n, scores_out, loss, accumulate, stream);
+}
+
+int clip_ce_loss(const float* logits, const int32_t* labels, int32_t n, int32_t n_classes, float* row_loss,
+                 float* loss, int32_t accumulate, void* stream) {
+  if (!logits || !labels || !row_loss || !loss || n < 0 || n_classes < 1)
+    return fail(CLIP_ERR_ARG, "clip_ce_loss: bad argument");
+  HIP_TRY(launch_ce_rows(logits, n_classes, n_classes, labels, n, row_loss, nullptr, (hipStream_t)stream));
+  HIP_TRY(launch_mean_loss(row_loss, n, loss, accumulate, (hipStream_t)stream));
+  return CLIP_OK;
 }
 
 int clip_set_fused_layernorm(clip_engine* e, int32_t on) {

@@ -341,12 +341,14 @@ hipError_t KSET::launch_gemm(const GemmArgs& g, hipStream_t st) {
 #endif
   if (g.res_index && g.tile == 2) return hipErrorInvalidValue;
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
-                      !(g.epi == EPI_BIAS_TANH && g.out_f32) && !g.res_index && g.epi != EPI_BIAS_RES16))
+                      !((g.epi == EPI_BIAS_TANH || g.epi == EPI_BIAS_GELU) && g.out_f32) && !g.res_index &&
+                      g.epi != EPI_BIAS_RES16))
     return launch_gemm8(g, st);
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_one<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_one<EPI_BIAS, true>(g, st);
     case EPI_BIAS_GELU * 2 + 0: return launch_one<EPI_BIAS_GELU, false>(g, st);
+    case EPI_BIAS_GELU * 2 + 1: return launch_one<EPI_BIAS_GELU, true>(g, st);   // LM-head transform (exact erf form)
     case EPI_BIAS_RES * 2 + 1: return launch_one<EPI_BIAS_RES, true>(g, st);
     case EPI_BIAS_RES * 2 + 0: return launch_one<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_one<EPI_BIAS_TANH, false>(g, st);

@@ -72,6 +72,12 @@ hipError_t launch_epilogue(const float* logits, const double* label_thresh, floa
 hipError_t launch_bce_loss(const float* logits, const float* targets, int count, float* loss,
                            hipStream_t st);
 
+// CrossEntropyLoss pieces (ref: bert_model.py:177-182): row_loss[i] = logsumexp(scores[i, :V]) - scores[i, labels[i]]
+// (copy: optional dense [n, V] copy of the rows), and loss[0] (+)= mean(row_loss)
+hipError_t launch_ce_rows(const float* scores, int ld, int V, const int32_t* labels, int n,
+                          float* row_loss, float* copy, hipStream_t st);
+hipError_t launch_mean_loss(const float* row_loss, int n, float* loss, int accumulate, hipStream_t st);
+
 // ---- launchers of the kernels that touch 16-bit operands: one set per operand type.  Every kernel
 // file is compiled twice (common.h: CLIP_OPERAND_F16) and defines KSET::launch_* ; the engine picks
 // the set by its precision (k_bf16 also holds the fp32 check-mode instantiations).

@@ -321,6 +321,55 @@ __global__ __launch_bounds__(256) void poison_logits_kernel(const int32_t* __res
   if (i < count && *err != 0) logits[i] = __builtin_nanf("");
 }
 
+// CrossEntropyLoss rows (ref: sentclf/bert_model.py:177-182, torch CrossEntropyLoss = log_softmax + NLL):
+// row_loss[i] = logsumexp(scores[i, 0:V]) - scores[i, labels[i]], one workgroup per row, fp32.
+// copy (optional) receives the first V columns of the row, dense [n, V] (the scores may be padded).
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ scores, int ld, int V,
+                                                      const int32_t* __restrict__ labels,
+                                                      float* __restrict__ row_loss,
+                                                      float* __restrict__ copy) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* row = scores + (size_t)i * ld;
+  float mx = -INFINITY;
+  for (int c = tid; c < V; c += 256) {
+    const float v = row[c];
+    mx = fmaxf(mx, v);
+    if (copy) copy[(size_t)i * V + c] = v;
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += expf(row[c] - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    const int lab = labels[i];
+    const float lse = mx + logf((red[0] + red[1]) + (red[2] + red[3]));
+    row_loss[i] = (lab >= 0 && lab < V) ? lse - row[lab] : __builtin_nanf("");
+  }
+}
+
+// loss[0] = (accumulate ? loss[0] : 0) + sum(row_loss[0:n]) / n, one workgroup, fixed summation order
+// (deterministic); n == 0 gives NaN as torch's mean over no elements does.
+__global__ __launch_bounds__(256) void mean_loss_kernel(const float* __restrict__ row_loss, int n,
+                                                        float* __restrict__ loss, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += row_loss[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = n > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (float)n : __builtin_nanf("");
+    loss[0] = (accumulate ? loss[0] : 0.f) + m;
+  }
+}
+
 template <typename F>
 hipError_t ln_dispatch(int H, bool f32, F&& f) {
 #define LN_CASE(h, v, n) \
@@ -423,6 +472,18 @@ hipError_t launch_bce_loss(const float* logits, const float* targets, int count,
                            hipStream_t st) {
   if (count <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(bce_loss_kernel, dim3(1), dim3(256), 0, st, logits, targets, count, loss);
+  return hipGetLastError();
+}
+
+hipError_t launch_ce_rows(const float* scores, int ld, int V, const int32_t* labels, int n,
+                          float* row_loss, float* copy, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, st, scores, ld, V, labels, row_loss, copy);
+  return hipGetLastError();
+}
+
+hipError_t launch_mean_loss(const float* row_loss, int n, float* loss, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(mean_loss_kernel, dim3(1), dim3(256), 0, st, row_loss, n, loss, accumulate);
   return hipGetLastError();
 }
 

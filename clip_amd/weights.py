@@ -16,7 +16,8 @@ import torch
 from .config import BertConfig
 
 
-def state_dict_shapes(cfg: BertConfig):
+def state_dict_shapes(cfg: BertConfig, mlm_head: bool = False):
+    """mlm_head: also the BertLMPredictionHead of BertContextMLMSwitch (bert_model.py:113), 207 keys."""
     H, I = cfg.hidden_size, cfg.intermediate_size
     s = {
         "bert.embeddings.word_embeddings.weight": (cfg.vocab_size, H),
@@ -44,6 +45,14 @@ def state_dict_shapes(cfg: BertConfig):
     s["bert.pooler.dense.bias"] = (H,)
     s["classifier.weight"] = (cfg.num_labels, H)
     s["classifier.bias"] = (cfg.num_labels,)
+    if mlm_head:
+        s["mlm_predictions.bias"] = (cfg.vocab_size,)
+        s["mlm_predictions.transform.dense.weight"] = (H, H)
+        s["mlm_predictions.transform.dense.bias"] = (H,)
+        s["mlm_predictions.transform.LayerNorm.weight"] = (H,)
+        s["mlm_predictions.transform.LayerNorm.bias"] = (H,)
+        s["mlm_predictions.decoder.weight"] = (cfg.vocab_size, H)
+        s["mlm_predictions.decoder.bias"] = (cfg.vocab_size,)
     return s
 
 
@@ -51,11 +60,11 @@ def state_dict_keys(cfg: BertConfig):
     return list(state_dict_shapes(cfg).keys())
 
 
-def procedural_state_dict(cfg: BertConfig, seed: int = 0, weight_std: float = 0.02):
+def procedural_state_dict(cfg: BertConfig, seed: int = 0, weight_std: float = 0.02, mlm_head: bool = False):
     """name -> fp32 torch tensor. Linear/embedding weights and biases ~ N(0, weight_std);
     LayerNorm gamma = 1 + 0.1 N(0,1), beta = 0.1 N(0,1) so the affine part is exercised."""
     out = {}
-    for name, shape in state_dict_shapes(cfg).items():
+    for name, shape in state_dict_shapes(cfg, mlm_head).items():
         g = np.random.Generator(np.random.Philox(key=[seed, zlib.crc32(name.encode())]))
         x = g.standard_normal(shape, dtype=np.float32)
         if "LayerNorm.weight" in name:

@@ -119,6 +119,24 @@ int clip_epilogue(const float* dev_logits, const double* dev_label_thresh, float
 int clip_bce_loss(const float* dev_logits, const float* dev_targets, int32_t count,
                   float* dev_loss, void* stream);
 
+/* The LM prediction head + CrossEntropyLoss of BertContextMLMSwitch.forward (bert_model.py:113,165,
+ * 175-179; transformers BertLMPredictionHead: dense H->H + erf-GELU + LayerNorm, decoder H->vocab + bias),
+ * for task-targeted pre-training's evaluation pass (weights mlm_predictions.* loaded
+ * with clip_load_weight).  Works on the last hidden state the LATEST clip_forward_packed on this engine left
+ * behind, which must have run with clip_set_trim_last_layer(e, 0).  dev_rows[i] is a packed token index
+ * whose MLM label dev_labels[i] is a vocabulary id: CrossEntropyLoss ignores label -100, so the caller
+ * passes only the labelled positions and the decoder runs on those rows alone.
+ *   dev_loss[0] = (accumulate ? dev_loss[0] : 0) + mean_i(logsumexp(scores_i) - scores_i[label_i])
+ * (NaN for n_rows == 0, as torch's mean over no elements); dev_scores_out (optional) receives the fp32
+ * scores [n_rows, vocab] (mlm_scores of bert_model.py:165 at those positions).  The head's workspace
+ * (n_rows x padded vocabulary of fp32) is allocated on first use and grows with n_rows. */
+int clip_mlm_head(clip_engine* e, const int32_t* dev_rows, const int32_t* dev_labels, int32_t n_rows,
+                  float* dev_scores_out, float* dev_loss, int32_t accumulate, void* stream);
+/* CrossEntropyLoss(logits [n, n_classes] fp32, labels int32) as bert_model.py:182 applies it to the switch
+ * logits: dev_row_loss[i] = logsumexp(logits_i) - logits_i[label_i]; dev_loss[0] (+)= their mean. */
+int clip_ce_loss(const float* dev_logits, const int32_t* dev_labels, int32_t n, int32_t n_classes,
+                 float* dev_row_loss, float* dev_loss, int32_t accumulate, void* stream);
+
 /* ---- single-kernel entry points (parity tests drive each kernel through the ABI) ---- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias): epi 0 bias, 1 bias+erf-GELU, 2 bias+residual, 3 bias+tanh
  * (modeling_bert.py:175-177, 289-293, 334-337, 347-351, 457-463). A, W, res are bf16; out bf16 or

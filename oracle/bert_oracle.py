@@ -127,6 +127,29 @@ def sentence_forward(sd, cfg, input_ids, attention_mask=None, token_type_ids=Non
     return F.binary_cross_entropy_with_logits(logits, labels), logits
 
 
+def mlm_switch_forward(sd, cfg, input_ids, attention_mask=None, token_type_ids=None, labels=None,
+                       mlm_labels=None, sep_token_id=102, n_context_sentences=2):
+    """BertContextMLMSwitch.forward (ref: sentclf/bert_model.py:137-186).  mlm_scores =
+    BertLMPredictionHead(last_hidden): dense + gelu + LayerNorm, decoder H -> vocab + bias (tf
+    BertPredictionHeadTransform / BertLMPredictionHead); switch logits = classifier(focus [SEP] row);
+    total_loss = CrossEntropy(mlm_scores, mlm_labels) (ignore_index -100) + CrossEntropy(logits, labels).
+    Returns (total_loss, logits, mlm_scores) — the reference returns the first two."""
+    x, _ = bert_model(sd, cfg, input_ids, attention_mask, token_type_ids)
+    pooled = collect_focus_repr(x, input_ids, sep_token_id, n_context_sentences)
+    t = x @ sd["mlm_predictions.transform.dense.weight"].T + sd["mlm_predictions.transform.dense.bias"]
+    t = layer_norm(gelu_erf(t), sd["mlm_predictions.transform.LayerNorm.weight"],
+                   sd["mlm_predictions.transform.LayerNorm.bias"], cfg.layer_norm_eps)
+    dec_bias = sd.get("mlm_predictions.decoder.bias", sd.get("mlm_predictions.bias"))
+    mlm_scores = t @ sd["mlm_predictions.decoder.weight"].T + dec_bias
+    logits = pooled @ sd["classifier.weight"].T + sd["classifier.bias"] if labels is not None else None
+    total = None
+    if mlm_labels is not None:
+        total = F.cross_entropy(mlm_scores.view(-1, mlm_scores.shape[-1]), mlm_labels.view(-1))
+        if labels is not None:
+            total = total + F.cross_entropy(logits.view(-1, 2), labels.view(-1))
+    return total, logits, mlm_scores
+
+
 # --------------------------------------------------------------------------- scoring epilogue
 def score_epilogue(logits, any_threshold=0.05):
     """ref: sentclf/apply_bert_unlabeled.py:111-124. p = sigmoid(logits) in fp32;

@@ -133,6 +133,64 @@ def make_case(name, cfg, seed, rows, n_ctx, batch_size=8, weights="procedural"):
     print(name, "done", logits.shape, "logit range", logits.min(), logits.max())
 
 
+def make_mlm_case(name, cfg, seed, rows, n_ctx, batch_size=8):
+    """BertContextMLMSwitch (sentclf/bert_model.py:106-186) of the reference: total loss and switch logits as
+    its forward returns them, plus its own LM head's scores at the labelled positions (summarised: logsumexp,
+    score of the label, argmax, 32 sampled columns)."""
+    import bert_model as ref_model
+    from clip_amd.weights import procedural_state_dict
+    from clip_amd.constants import SEP_ID
+    sd = procedural_state_dict(cfg, seed, mlm_head=True)
+    hc = hf_config(cfg)
+    model = ref_model.BertContextMLMSwitch(hc)
+    print(name, "load_state_dict:", model.load_state_dict(sd, strict=True), "keys:", len(model.state_dict()))
+    model.set_sep_token_id(SEP_ID); model.set_n_context_sentences(n_ctx); model.set_task("binary")
+    model.eval()
+    rng = np.random.default_rng(seed + 1)
+    cols = rng.choice(cfg.vocab_size, 32, replace=False).astype(np.int64)
+    masked_rows, mlm_flat, switch, losses, logits_all, lse, lab_score, amax, sampled = [], [], [], [], [], [], [], [], []
+    with torch.no_grad():
+        for i in range(0, len(rows), batch_size):
+            batch = [np.array(r, np.int64) for r in rows[i:i + batch_size]]
+            labs = []
+            for r in batch:                  # mask ~15 % of the focus sentence (between [SEP] n and [SEP] n+1)
+                seps = np.flatnonzero(r == SEP_ID)
+                lo, hi = seps[n_ctx - 1] + 1, seps[n_ctx]
+                lab = np.full(len(r), -100, np.int64)
+                pick = np.flatnonzero(rng.random(hi - lo) < 0.15) + lo
+                if len(pick) == 0 and hi > lo:
+                    pick = np.array([lo])
+                lab[pick] = r[pick]
+                r[pick] = 103                # [MASK]
+                labs.append(lab)
+            ids, mask = pad(batch)
+            mlm = torch.full(ids.shape, -100, dtype=torch.long)
+            for k, lab in enumerate(labs):
+                mlm[k, :len(lab)] = torch.from_numpy(lab)
+            sw = torch.from_numpy(rng.integers(0, 2, len(batch)))
+            tt = ref_token_types(ids, SEP_ID, n_ctx)
+            loss, logits = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=sw, mlm_labels=mlm)[:2]
+            scores = model.mlm_predictions(model.bert(ids, attention_mask=mask, token_type_ids=tt)[0])
+            sel = mlm != -100
+            sc = scores[sel]
+            lse.append(torch.logsumexp(sc, -1).numpy()); amax.append(sc.argmax(-1).numpy())
+            lab_score.append(sc.gather(1, mlm[sel][:, None])[:, 0].numpy()); sampled.append(sc[:, cols].numpy())
+            masked_rows += batch; mlm_flat += labs; switch.append(sw.numpy())
+            losses.append(float(loss)); logits_all.append(logits.numpy().copy())
+            print(f"  ref mlm batch {i // batch_size}: S={ids.shape[1]} labelled={int(sel.sum())} loss={float(loss):.4f}", flush=True)
+    ids, lens = pack(masked_rows)
+    from dataclasses import asdict
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        cfg=np.asarray([str(asdict(cfg))]), seed=np.int64(seed), n_ctx=np.int64(n_ctx), weights=np.asarray(["procedural"]),
+        batch_size=np.int64(batch_size), ids=ids, lens=lens, mlm_labels=np.concatenate(mlm_flat).astype(np.int32),
+        switch_labels=np.concatenate(switch).astype(np.int64), ref_batch_loss=np.asarray(losses, np.float32),
+        ref_logits=np.concatenate(logits_all).astype(np.float32), ref_lse=np.concatenate(lse).astype(np.float32),
+        ref_label_score=np.concatenate(lab_score).astype(np.float32), ref_argmax=np.concatenate(amax).astype(np.int32),
+        sample_cols=cols, ref_sampled=np.concatenate(sampled).astype(np.float32))
+    print(name, "done: losses", losses)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -182,6 +240,16 @@ def main():
     make_case("base_ctx_stress", base, 9, rows, 2, weights="trained_like")
     rows = synth.sentence_rows(32, base.vocab_size, max_len=64, seed=35)
     make_case("base_sent_stress", base, 10, rows, 0, weights="trained_like")
+
+    # BertContextMLMSwitch (LM head + switch classifier), num_labels = 2
+    from dataclasses import replace
+    if not only or "tiny_mlm" in only:
+        rows = synth.context_rows(20, 2, tiny.vocab_size, max_len=96, seed=41)
+        make_mlm_case("tiny_mlm", replace(tiny, num_labels=2), 11, rows, 2)
+    if not only or "base_mlm" in only:
+        rows = synth.context_rows(14, 2, base.vocab_size, max_len=256, seed=42)
+        rows += synth.context_rows(2, 2, base.vocab_size, max_len=512, seed=43, fixed_len=512)
+        make_mlm_case("base_mlm", replace(base, num_labels=2), 12, rows, 2)
 
 
 if __name__ == "__main__":
