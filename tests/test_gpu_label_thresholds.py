@@ -49,7 +49,7 @@ def test_fit_label_thresholds_through_the_engine(tmp_path, precision):
     for j, label in enumerate(LABEL_TYPES):
         if thr_gpu[j] != thr_cpu[j]:
             f1 = LT.threshold_metrics(p_ref[:, j], y[:, j], thresholds=np.array([thr_gpu[j], thr_cpu[j]]))["f1"]
-            assert abs(f1[0] - f1[1]) < 1e-3, (label, thr_gpu[j], thr_cpu[j], f1)
+            assert abs(f1[0] - f1[1]) < (3e-3 if precision == "bf16" else 1e-3), (label, thr_gpu[j], thr_cpu[j], f1)
     assert abs(metrics_gpu["balanced-macro-f1"] - metrics_cpu["balanced-macro-f1"]) < 5e-3
     assert abs(metrics_gpu["balanced-macro-auc"] - metrics_cpu["balanced-macro-auc"]) < 5e-3
     # the artefact the scoring path loads (test_load.py:29): float64[7], round trip
