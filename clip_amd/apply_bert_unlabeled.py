@@ -21,18 +21,22 @@ all-gather.
 """
 import argparse
 import os
+import queue
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
 
 import torch
 
 from . import launch, topk as topk_mod
 from .bert_model import args_to_model
-from .fast_tokenizer import FastWordPiece, build_rows_fast
+from .fast_tokenizer import FastWordPiece, build_rows_chunks, build_rows_fast
 from .config import BertConfig
 from .constants import LABEL_TYPES
 from .datasets import SentDataset, SentEvalDataset
-from .columnar import ColumnarCorpus, save_rows
+from .columnar import ColumnarCorpus, chunk_bounds, save_rows
 from .job import RunningTopK, write_topk_csv
-from .scoring import BulkScorer, write_ttp_csv
+from .scoring import BulkScorer, PackedRows, write_ttp_csv
 
 
 def main(argv=None):
@@ -71,10 +75,32 @@ def main(argv=None):
     if not args.tokenize_only:
         dist, rank, world, device = launch.init_distributed()
 
+    # ---- model + engine (:55-80), built on a helper thread while this one tokenises: reading the weights,
+    # rounding them and allocating the workspace (HIP calls, which release the GIL) overlap the C++ tokenizer
+    def build_model():
+        config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
+        model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,
+                                                        max_seqs=max(64, args.tokens_per_step // 8))  # :64-70
+        if args.local_weights.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(args.local_weights)
+        else:
+            sd = torch.load(args.local_weights, map_location="cpu", weights_only=True)       # :78
+        model.load_state_dict(sd)                                                          # :79
+        model.set_precision(args.precision)
+        model.to(device).eval()                                                            # :72,100
+        with torch.cuda.device(device):
+            model._ensure_engine()
+        return model
+
+    pool = ThreadPoolExecutor(max_workers=3)
+    build = pool.submit(build_model) if not args.tokenize_only else None
+
     # ---- rows: a columnar directory as it is, or the CSV through the C++ front end — ONCE per job:
     # rank 0 tokenises on all host cores and writes the columnar directory, every rank memory-maps it
     # (N ranks tokenising the same CSV would be N x the work on the same cores)
     out_dir = os.path.dirname(args.local_weights) or "."                               # :90
+    stream = None            # single rank, CSV input: (dataset, tokenizer, bounds) of the pipelined tokenizer
     if os.path.isdir(args.unlabeled_fname):
         corpus_dir = args.unlabeled_fname
         corpus = None
@@ -89,39 +115,35 @@ def main(argv=None):
             else:
                 dataset = SentEvalDataset(args.unlabeled_fname, args.task,
                                           n_context_sentences=args.n_context_sentences)
-            rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
             meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=tokenizer.sep_token_id,
                         cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
                         source=os.path.basename(args.unlabeled_fname))
-            if corpus_dir:
-                save_rows(corpus_dir, rows, doc_ids, sent_ixs, **meta)
-            if world == 1:
-                corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
+            if world == 1 and not args.tokenize_only:
+                # one rank: tokenise in pieces of whole documents on a helper thread WHILE the GPU scores the
+                # piece before (any chunking gives the same files: parts are concatenated in order and the
+                # top-k is a running merge)
+                stream = (dataset, tokenizer, chunk_bounds(dataset.doc_ids, min(args.chunk_rows, 100_000)), meta)
+            else:
+                rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
+                if corpus_dir:
+                    save_rows(corpus_dir, rows, doc_ids, sent_ixs, **meta)
+                if world == 1:
+                    corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
         if dist is not None:
             dist.barrier()
-    if corpus is None:
+    if corpus is None and stream is None:
         corpus = ColumnarCorpus(corpus_dir)
         if corpus.meta.get("n_context_sentences") != args.n_context_sentences:
             raise ValueError(f"{corpus_dir} was tokenised with n_context_sentences="
                              f"{corpus.meta.get('n_context_sentences')}, not {args.n_context_sentences}")
-    sep_id = int(corpus.meta["sep_token_id"])
+    sep_id = int((corpus.meta if corpus is not None else stream[3])["sep_token_id"])
     if args.tokenize_only:
         if not args.save_rows:
             raise ValueError("--tokenize_only needs --save_rows")
         print(f"tokenised {len(corpus)} rows / {corpus.meta['tokens']} tokens -> {args.save_rows}")
         return None
 
-    config = BertConfig.from_pretrained(args.model, num_labels=len(LABEL_TYPES))       # :55-62
-    model = args_to_model(args.n_context_sentences)(config, max_tokens=args.tokens_per_step,
-                                                    max_seqs=max(64, args.tokens_per_step // 8))  # :64-70
-    if args.local_weights.endswith(".safetensors"):
-        from safetensors.torch import load_file
-        sd = load_file(args.local_weights)
-    else:
-        sd = torch.load(args.local_weights, map_location="cpu", weights_only=True)       # :78
-    model.load_state_dict(sd)                                                          # :79
-    model.set_precision(args.precision)
-    model.to(device).eval()                                                            # :72,100
+    model = build.result()
     if args.n_context_sentences > 0:
         model.set_sep_token_id(sep_id)                                                 # :74
         model.set_n_context_sentences(args.n_context_sentences)                        # :75
@@ -131,23 +153,60 @@ def main(argv=None):
     # running top-k.  Chunks are whole documents; chunk c belongs to rank c mod world.
     scorer = BulkScorer(model, any_threshold=args.threshold)
     out = os.path.join(out_dir, "ttp_doc_sents.csv")
-    n_chunks = len(corpus.chunk_bounds(args.chunk_rows))
+    def chunk_source():
+        if stream is None:
+            for c, a, b, item in corpus.chunks(args.chunk_rows, rank, world):
+                yield (c,) + item
+            return
+        dataset, tokenizer, bounds, meta = stream
+        q = queue.Queue(maxsize=2)
+
+        def produce():
+            try:
+                for c, item in enumerate(build_rows_chunks(dataset, tokenizer, args.n_context_sentences, bounds)):
+                    q.put((c,) + item)
+                q.put(None)
+            except BaseException as exc:      # surfaces in the consumer
+                q.put(exc)
+
+        pool.submit(produce)
+        kept = []
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            if args.save_rows:
+                kept.append(item[1:])
+            yield item
+        if args.save_rows:
+            lens = np.concatenate([k[0].lens for k in kept]) if kept else np.zeros(0, np.int64)
+            rows = PackedRows(np.concatenate([k[0].flat for k in kept]) if kept else np.zeros(0, np.int32),
+                              np.concatenate(([0], np.cumsum(lens, dtype=np.int64))))
+            save_rows(args.save_rows, rows, np.concatenate([k[1] for k in kept]), np.concatenate([k[2] for k in kept]), **meta)
+
+    n_chunks = len(stream[2]) if stream is not None else len(corpus.chunk_bounds(args.chunk_rows))
     top = RunningTopK(args.topk) if args.topk > 0 else None
     n_rows = n_kept = 0
     res = None
-    for c, a, b, (rows_c, d_c, s_c) in corpus.chunks(args.chunk_rows, rank, world):
+    writes = []
+    for c, rows_c, d_c, s_c in chunk_source():
         res = scorer.score(rows_c, d_c, s_c)
-        write_ttp_csv(f"{out}.chunk{c}", res)
+        writes.append(pool.submit(write_ttp_csv, f"{out}.chunk{c}", res))      # formatted while the next chunk is scored
         if top is not None:
             top.update(res.doc_ids, res.sent_ixs, res.max_score, keep=res.keep)
         n_rows += len(res.keep)
         n_kept += int(res.keep.sum())
+    for w in writes:
+        w.result()
+    pool.shutdown()
     if dist is not None:
         dist.barrier()
     if rank == 0:                                       # parts in chunk order = input order (:97-98,124)
-        with open(out, "w") as f:
+        with open(out, "wb") as f:                      # bytes: csv.writer's '\r\n' row ends stay as the reference writes them
             for c in range(n_chunks):
-                with open(f"{out}.chunk{c}") as g:
+                with open(f"{out}.chunk{c}", "rb") as g:
                     f.write(g.read())
                 os.remove(f"{out}.chunk{c}")
     if top is not None:

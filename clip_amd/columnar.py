@@ -40,6 +40,25 @@ def save_rows(path, rows: PackedRows, doc_ids, sent_ixs, **meta):
         json.dump(meta, f, indent=1)
 
 
+def chunk_bounds(doc_ids, chunk_rows):
+    """Row ranges of about chunk_rows rows that end on document boundaries (rows of a document are
+    contiguous, as in the reference's CSVs).  A document longer than chunk_rows is one chunk."""
+    d = np.asarray(doc_ids)
+    n = len(d)
+    if n == 0:
+        return []
+    starts = np.concatenate(([0], np.flatnonzero(d[1:] != d[:-1]) + 1, [n]))     # first row of each document, then n
+    bounds, a = [], 0
+    while a < n:
+        k = int(np.searchsorted(starts, a + chunk_rows, side="right")) - 1      # last boundary <= a + chunk_rows
+        b = int(starts[k])
+        if b <= a:                                                               # one long document
+            b = int(starts[int(np.searchsorted(starts, a, side="right"))])
+        bounds.append((a, b))
+        a = b
+    return bounds
+
+
 class ColumnarCorpus:
     @classmethod
     def from_arrays(cls, rows: PackedRows, doc_ids, sent_ixs, **meta):
@@ -71,23 +90,7 @@ class ColumnarCorpus:
                 np.asarray(self.sent_ixs[a:b]))
 
     def chunk_bounds(self, chunk_rows):
-        """Row ranges of about chunk_rows rows that end on document boundaries (rows of a document are
-        contiguous, as in the reference's CSVs).  A document longer than chunk_rows is one chunk."""
-        n = len(self)
-        if n == 0:
-            return []
-        d = np.asarray(self.doc_ids)
-        starts = np.concatenate(([0], np.flatnonzero(d[1:] != d[:-1]) + 1, [n]))     # first row of each document, then n
-        bounds, a = [], 0
-        while a < n:
-            k = int(np.searchsorted(starts, a + chunk_rows, side="right")) - 1      # last boundary <= a + chunk_rows
-            b = int(starts[k])
-            if b <= a:                                                               # one long document
-                b = int(starts[int(np.searchsorted(starts, a, side="right"))])
-            bounds.append((a, b))
-            a = b
-        return bounds
-
+        return chunk_bounds(self.doc_ids, chunk_rows)
     def chunks(self, chunk_rows, rank=0, world=1):
         for c, (a, b) in enumerate(self.chunk_bounds(chunk_rows)):
             if c % world == rank:

@@ -7,6 +7,7 @@ said where it applies.
 """
 import ast
 
+import numpy as np
 import pandas as pd
 
 
@@ -49,6 +50,22 @@ class SentDataset:
 
     def __len__(self):
         return len(self.sents)
+
+    def take(self, idx):
+        """A dataset over the rows idx (in that order) of this one: the same object shape over sliced
+        columns, nothing re-read.  A row's neighbours are then its neighbours IN idx (the reference looks
+        them up by row offset, neural_baselines.py:219-235), which is what the chunked tokenizer relies on."""
+        import copy
+        sub = copy.copy(self)
+        idx = np.asarray(idx, np.int64)
+        sub.sents = self.sents.iloc[idx]
+        sub.doc_ids = self.doc_ids[idx]
+        sub.sent_ixs = None if self.sent_ixs is None else self.sent_ixs[idx]
+        sub._sentence = [self._sentence[i] for i in idx]
+        sub._labels = None if self._labels is None else [self._labels[i] for i in idx]
+        if getattr(self, "_annot", None) is not None:
+            sub._annot = [self._annot[i] for i in idx]
+        return sub
 
     def _row_labels(self, idx):
         if self.task == "multilabel":

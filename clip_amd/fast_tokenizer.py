@@ -221,3 +221,23 @@ def build_rows_fast(dataset, tokenizer: FastWordPiece, n_context_sentences):
     for i, a in special.items():
         out[off[i]:off[i + 1]] = a
     return PackedRows(out, off), doc_ids, np.asarray(ix, np.int64)
+
+
+def build_rows_chunks(dataset, tokenizer: FastWordPiece, n_context_sentences, bounds):
+    """build_rows_fast in pieces: yields (PackedRows, doc_ids, sent_ixs) for each row range (a, b) of
+    `bounds`, identical to slicing the whole-file result — so a consumer (the GPU) can start on the first
+    chunk while the next is being tokenised.  A row's context is looked up by row OFFSET
+    (neural_baselines.py:219-235), so each piece is built over its rows plus a halo of n rows on either
+    side; a negative position wraps to the END of the file (pandas .iloc), so the first pieces also carry
+    the file's last n rows at their end."""
+    from .scoring import PackedRows
+    n, N = int(n_context_sentences), len(dataset)
+    for a, b in bounds:
+        lo, hi = max(0, a - n), min(N, b + n)
+        idx = np.arange(lo, hi)
+        if n and a - n < 0:
+            idx = np.concatenate((idx, np.arange(max(hi, N - n), N)))
+        rows, d, s = build_rows_fast(dataset.take(idx), tokenizer, n)
+        i0, i1 = a - lo, a - lo + (b - a)
+        o = rows.offsets[i0:i1 + 1]
+        yield PackedRows(rows.flat[o[0]:o[-1]], o - o[0]), d[i0:i1], s[i0:i1]

@@ -192,10 +192,16 @@ def write_ttp_csv(path, result: ScoreResult):
     """ttp_doc_sents.csv as the reference writes it (apply_bert_unlabeled.py:97-98,124): no header,
     rows `doc_id,sent_ix,max_label_score` for the kept sentences in input order, the score printed
     as str(numpy.float32)."""
+    # csv.writer's format (fields joined by ',', rows ended by '\r\n'; ints and str(np.float32) need no
+    # quoting), built with array operations: numpy's float32 -> str is the same shortest-repr text
+    sel = np.nonzero(result.keep)[0]
     with open(path, "w", newline="") as f:
-        w = csv.writer(f)
-        for i in np.nonzero(result.keep)[0]:
-            w.writerow([result.doc_ids[i], result.sent_ixs[i], result.max_score[i]])
+        if len(sel):
+            d = result.doc_ids[sel].astype(str)
+            s = np.asarray(result.sent_ixs)[sel].astype(str)
+            m = np.asarray(result.max_score, np.float32)[sel].astype(str)
+            lines = np.char.add(np.char.add(np.char.add(np.char.add(d, ","), s), ","), m)
+            f.write("\r\n".join(lines.tolist()) + "\r\n")
 
 
 def read_ttp_csv(path):

@@ -206,3 +206,26 @@ def test_ascii_only_flag_hands_back_every_non_ascii_string(fast):
         assert _rows_of(flat, off) == [fast.py.encode_plain(t) for t in texts]
     finally:
         fast.mode_flags = saved
+
+
+@pytest.mark.parametrize("n,chunk", [(2, 7), (2, 1), (1, 13), (0, 5), (2, 10**6)])
+def test_chunked_build_equals_whole_file_build(n, chunk):
+    """build_rows_chunks (the pipelined form the CLI feeds the GPU from) == slices of build_rows_fast, incl.
+    the wrap of negative row positions to the end of the file and the duplicated / gapped sentence indices of
+    the fixtures."""
+    import os
+    from clip_amd import columnar, datasets
+    from clip_amd.fast_tokenizer import FastWordPiece, build_rows_chunks, build_rows_fast
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    tok = FastWordPiece(os.path.join(G, "vocab.txt"))
+    for fname in ("notes_synth.csv", "dummy_test_data.csv"):
+        path = os.path.join(G, fname)
+        ds = datasets.SentEvalDataset(path, "multilabel", n_context_sentences=n) if n else datasets.SentDataset(path, "multilabel")
+        whole, d, s = build_rows_fast(ds, tok, n)
+        bounds = columnar.chunk_bounds(ds.doc_ids, chunk)
+        assert bounds[0][0] == 0 and bounds[-1][1] == len(ds)
+        got = list(build_rows_chunks(ds, tok, n, bounds))
+        flat = np.concatenate([g[0].flat for g in got])
+        lens = np.concatenate([g[0].lens for g in got])
+        assert np.array_equal(flat, whole.flat) and np.array_equal(lens, whole.lens)
+        assert np.array_equal(np.concatenate([g[1] for g in got]), d) and np.array_equal(np.concatenate([g[2] for g in got]), s)

@@ -40,3 +40,26 @@ def test_ttp_csv_format_matches_reference_writer(tmp_path):
     assert lines == ["10,0,0.5", "11,0," + str(np.float32(0.123456789))] == ["10,0,0.5", "11,0,0.12345679"]
     d, s, m = scoring.read_ttp_csv(p)
     assert d.tolist() == [10, 11] and s.tolist() == [0, 0] and m[1] == np.float32(0.123456789)
+
+
+def test_ttp_csv_bytes_equal_the_csv_writer_form(tmp_path):
+    """write_ttp_csv builds the file with array operations; byte for byte what the reference's
+    csv.writer.writerow([doc_id, sent_ix, np.float32]) loop writes (apply_bert_unlabeled.py:97-98,124)."""
+    import csv
+    from clip_amd.scoring import ScoreResult, read_ttp_csv, write_ttp_csv
+    rng = np.random.default_rng(1)
+    n = 5000
+    score = np.concatenate([rng.random(n - 8).astype(np.float32),
+                            np.float32([1e-5, 1e-7, 0.5, 1.0, 0.05, 3.4e-8, 0.99999994, 1e-10])])
+    res = ScoreResult(rng.integers(0, 10**9, n), rng.integers(0, 400, n), score, rng.random(n) < 0.7, None, None)
+    write_ttp_csv(tmp_path / "a.csv", res)
+    with open(tmp_path / "b.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        for i in np.nonzero(res.keep)[0]:
+            w.writerow([res.doc_ids[i], res.sent_ixs[i], res.max_score[i]])
+    assert (tmp_path / "a.csv").read_bytes() == (tmp_path / "b.csv").read_bytes()
+    d, s, m = read_ttp_csv(tmp_path / "a.csv")
+    assert np.array_equal(m, score[res.keep]) and np.array_equal(d, res.doc_ids[res.keep])
+    res.keep[:] = False
+    write_ttp_csv(tmp_path / "c.csv", res)
+    assert (tmp_path / "c.csv").read_bytes() == b""
