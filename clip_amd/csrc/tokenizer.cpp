@@ -526,6 +526,13 @@ int clip_tok_encode_plain(clip_tokenizer* t, const char* blob, const int64_t* of
     pool.emplace_back(run_chunk, std::cref(*t), blob, off, cut[k], cut[k + 1], mode, fallback, std::ref(chunks[k]));
   run_chunk(*t, blob, off, cut[0], cut[1], mode, fallback, chunks[0]);
   for (auto& th : pool) th.join();
+  // the up-front check above rests on "tokens emitted <= input bytes" (every token consumes at least one
+  // byte of its sentence); do not let a violation of that invariant become a write past the caller's buffer
+  int64_t need = 0;
+  for (int k = 0; k < T; ++k) need += (int64_t)chunks[k].ids.size();
+  if (need > ids_cap)
+    return fail(CLIP_TOK_ERR_CAPACITY, "clip_tok_encode_plain: %lld tokens exceed ids_cap %lld", (long long)need,
+                (long long)ids_cap);
   int64_t pos = 0, row = 0;
   for (int k = 0; k < T; ++k) {
     for (int64_t l : chunks[k].lens) { ids_off[row++] = pos; pos += l; }

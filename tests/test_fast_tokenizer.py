@@ -177,6 +177,9 @@ def test_unicode_path_matches_python_tokenizer(tmp_path, lower):
     texts = _fuzz_strings(4000, 7 + lower) + ["café ß Straße", "İstanbul", "ǅ ǆ", "각 한국어", "日本語", "a\u0301\u0323b", "¿qué?",
                                                "ςσ ΣΑΣ", "x\u2028y\u2029z", "[SEP]é[CLS]", "ﬁn"]
     flat, off, fb = f.encode_plain_many(texts)
+    # the invariant the library's output capacity rests on: no sentence yields more tokens than it has bytes
+    nbytes = np.array([len(t.encode("utf-8")) for t in texts])
+    assert (np.diff(off)[~fb] <= nbytes[~fb]).all() and off[-1] <= nbytes.sum()
     ref = [f.py.encode_plain(t) for t in texts]
     got = _rows_of(flat, off)
     bad = [i for i in range(len(texts)) if got[i] != ref[i]]
