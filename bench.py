@@ -28,7 +28,7 @@ from clip_amd.config import BertConfig  # noqa: E402
 from clip_amd.weights import procedural_state_dict  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_FILE = "r01_v10_pmc_traffic.json"
+PMC_FILE = "r02_pmc_traffic.json"
 DNOTE_THRESHS = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
 
 
@@ -186,7 +186,7 @@ def main():
             pass
         mfma_busy = None      # MFMA busy cycles / kernel cycles of the dominant kernel, from an SQ PMC pass kept under profiles/
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v10_pmc_mfma_util.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_util.json")) as fh:
                 mfma_busy = json.load(fh)["gemm8_kernel<1, false, false>"]["mfma_utilisation"]
         except (OSError, KeyError, ValueError):
             pass

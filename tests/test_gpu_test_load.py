@@ -1,4 +1,4 @@
-"""BASELINE.json config #1: the reference's test_load.py flow (examples/test_load.py) — local
+"""BASELINE.json config #1: the reference's test_load.py flow (examples/label_sentences.py) — local
 from_pretrained directory, setters, float64 per-label thresholds from .npy, SentEvalDataset over
 dummy_test_data.csv, DataLoader(batch_size=1) + ctx_collator + select_inputs, `loss, pred = model(**inputs)`,
 sigmoid, strict `>` against the thresholds, label names — against the CPU oracle doing the same."""
@@ -38,7 +38,7 @@ def test_reference_example_flow(tmp_path, fmt, capsys):
         torch.save(sd, ckpt / "pytorch_model.bin")
     shutil.copyfile(os.path.join(G, "vocab.txt"), ckpt / "vocab.txt")
     np.save(tmp_path / "clip_dnote_label_threshs.npy", DNOTE)
-    spec = importlib.util.spec_from_file_location("example_test_load", os.path.join(HERE, "..", "examples", "test_load.py"))
+    spec = importlib.util.spec_from_file_location("example_test_load", os.path.join(HERE, "..", "examples", "label_sentences.py"))
     ex = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ex)
     csv_path = os.path.join(G, "dummy_test_data.csv")
