@@ -43,7 +43,7 @@ constexpr int LDS8 = RING + 8 * SCR + 2 * 3072 + 4096;  // + {bias, ln gamma, ln
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 #ifndef GEMM8_ABLATE
-#define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue
+#define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue, 2 the whole epilogue except its global stores
 #endif
 #ifndef GEMM8_STORE
 #define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
@@ -59,6 +59,7 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 #endif
 template <typename V>
 __device__ __forceinline__ void out_store(V v, V* p) {
+  if (GEMM8_ABLATE == 2) { asm volatile("" ::"v"(v), "v"(p)); return; }
   if (GEMM8_STORE == 0) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
