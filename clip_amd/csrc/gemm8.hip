@@ -45,6 +45,9 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 #ifndef GEMM8_ABLATE
 #define GEMM8_ABLATE 0  // diagnostic builds: 1 no epilogue, 2 the whole epilogue except its global stores
 #endif
+#ifndef GEMM8_SPLIT
+#define GEMM8_SPLIT 0   // 1: the second half-tile of each phase's staging is issued in the middle of the phase's MFMA block
+#endif
 #ifndef GEMM8_STORE
 #define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
 #endif
@@ -56,6 +59,19 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
     reinterpret_cast<volatile uint32_t*>(lo.err)[64 + 8 * blockIdx.x + (k)] = (uint32_t)__builtin_amdgcn_s_memtime();
 #else
 #define LN_STAMP(k)
+#endif
+// diagnostic builds (-DGEMM8_STAMPS, tools/gemm8_stamps.py): waves 0 and 4 of every workgroup stamp the sections
+// of ONE K tile (second output tile, K tile 4) with s_memtime into a device array read back by
+// clip_debug_gemm8_stamps(); no output depends on it.  Slots: 0 phase-A start, 1 its loads retired, 2 past the
+// barrier, 3 MFMAs issued, 4 past the barrier = phase-B start, 5 loads retired, 6 past the barrier, 7 MFMAs
+// issued, 8 past the barrier.
+#ifdef GEMM8_STAMPS
+__device__ uint32_t g_gemm8_stamps[256 * 2 * 16];
+#define K_STAMP(k)                                                                             \
+  if (it == 1 && kk == 4 && B == 0 && lane == 0 && (w == 0 || w == 4))                          \
+    g_gemm8_stamps[(blockIdx.x * 2 + (w >> 2)) * 16 + (k)] = (uint32_t)__builtin_readcyclecounter();
+#else
+#define K_STAMP(k)
 #endif
 template <typename V>
 __device__ __forceinline__ void out_store(V v, V* p) {
@@ -141,7 +157,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   const bf16_t *a1, *w1, *a2, *w2;
   bool v1, v2;
   int s_it = 0, s_kt = 0, s_tm = tm, s_tn = tn;  // position of c2
-  auto advance = [&]() {  // c1 <- c2, c2 <- the K tile after c2
+  // c1 <- c2, c2 <- the K tile after c2.  Inside a tile the cursors just step by BK (two scalar adds each);
+  // the 64-bit products and tile_at's divisions run only at a tile change.  Called from phase B's load
+  // section, whose end waits for the partner group anyway — never between a barrier and the next K tile's
+  // first ds_read, where ~30 dependent scalar instructions used to delay the whole load section (stamps:
+  // ~250 cycles per K tile on the critical path).
+  auto advance = [&]() {
     a1 = a2; w1 = w2; v1 = v2;
     if (!v2) return;
     if (++s_kt == nt) {
@@ -149,9 +170,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       ++s_it;
       v2 = tile_at(s_it, s_tm, s_tn);
       if (!v2) return;
+      a2 = A + (size_t)s_tm * BM * lda;
+      w2 = W + (size_t)s_tn * BN * ldw;
+    } else {
+      a2 += BK;
+      w2 += BK;
     }
-    a2 = A + (size_t)s_tm * BM * lda + s_kt * BK;
-    w2 = W + (size_t)s_tn * BN * ldw + s_kt * BK;
   };
 
   // ---- prologue: K tile 0 whole, the bias slice, three half-tiles of K tile 1
@@ -202,6 +226,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     for (int kk = 0; kk < nt; kk += 2) {
       auto ktile = [&]<int B>() {
         const char* buf = smem + B * 4 * HT;
+        K_STAMP(0)
+#ifdef GEMM8_STAMPS
+        if (it == 1 && kk == 4 && B == 1 && lane == 0 && (w == 0 || w == 4))   // start of the NEXT K tile: slot 9
+          g_gemm8_stamps[(blockIdx.x * 2 + (w >> 2)) * 16 + 9] = (uint32_t)__builtin_readcyclecounter();
+#endif
         // ---------------- phase A: A0, both B n-halves -> acc[0][*]; stage (t+1).B1, (t+1).A1
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -220,21 +249,24 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         }
         if (v1) {
           stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
-          stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+          if (GEMM8_SPLIT == 0) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
           // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
           // (t).A1, read next phase, is older
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          if (GEMM8_SPLIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // younger than everything the wait above covers, older than phase B's DMA: retired by B's wait
         if (B == 1 && kk == 0 && has_next) stage_bias(ntn, (it + 1) & 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K_STAMP(1)
         __builtin_amdgcn_s_barrier();
+        K_STAMP(2)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -242,28 +274,43 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               acc[0][0][m][i] = MFMA_16x16x32(bf0[i][ks], af[m][ks], acc[0][0][m][i]);
               acc[0][1][m][i] = MFMA_16x16x32(bf1[i][ks], af[m][ks], acc[0][1][m][i]);
             }
+          if (GEMM8_SPLIT == 1 && ks == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (v1) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        K_STAMP(3)
         __builtin_amdgcn_s_barrier();
+        K_STAMP(4)
         // ---------------- phase B: A1 -> acc[1][*]; stage (t+2).A0, (t+2).B0; K tile t+1 retired
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           af[m][0] = *reinterpret_cast<const opx8_t*>(buf + 3 * HT + a_rd + m * 2048 + c0);
           af[m][1] = *reinterpret_cast<const opx8_t*>(buf + 3 * HT + a_rd + m * 2048 + c1);
         }
+        const bool staged2 = v2;
+        const bf16_t* w2_mid = w2;  // (GEMM8_SPLIT: the W half staged mid-block, after advance() moved the cursor)
         if (v2) {
           stage_half(a2, a_off, lda, B * 4 + 0);
-          stage_half(w2, w_off, ldw, B * 4 + 1);
+          if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ldw, B * 4 + 1);
+        }
+        advance();
+        if (staged2) {
           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        K_STAMP(5)
         __builtin_amdgcn_s_barrier();
+        K_STAMP(6)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -271,10 +318,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               acc[1][1][m][i] = MFMA_16x16x32(bf1[i][ks], af[m][ks], acc[1][1][m][i]);
               acc[1][0][m][i] = MFMA_16x16x32(bf0[i][ks], af[m][ks], acc[1][0][m][i]);
             }
+          if (GEMM8_SPLIT == 1 && ks == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (staged2) stage_half(w2_mid, w_off, ldw, B * 4 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        K_STAMP(7)
         __builtin_amdgcn_s_barrier();
-        advance();
+        K_STAMP(8)
       };
       ktile.template operator()<0>();
       ktile.template operator()<1>();
@@ -622,3 +676,11 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
     default: return hipErrorInvalidValue;
   }
 }
+
+#ifdef GEMM8_STAMPS
+#if !CLIP_OPERAND_F16
+extern "C" int clip_debug_gemm8_stamps(uint32_t* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm8_stamps), (size_t)n_words * 4);
+}
+#endif
+#endif
