@@ -80,6 +80,16 @@ __device__ __forceinline__ void out_store(V v, V* p) {
   else *p = v;
 }
 
+// v + (v of the lane 16 / 32 away): every lane of the pair ends with the sum
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int EPI, bool OUT_F32, bool RES_TILED = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -402,19 +412,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          float sm = 0.f, sq = 0.f;
+          // packed fp32 adds / fmas over the lane's 16 values, then the 4 lanes of a row (lane bits 4, 5) by
+          // v_permlane16_swap / v_permlane32_swap (VALU; the ds_bpermute form of __shfl_xor went through the LDS)
+          f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
           for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float v = acc[mh][nh][m][i][e];
-                sm += v;
-                sq = fmaf(v, v, sq);
-              }
-          sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
-          sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            for (int i = 0; i < 2; ++i) {
+              const f32x2_t lo = {acc[mh][nh][m][i][0], acc[mh][nh][m][i][1]};
+              const f32x2_t hi = {acc[mh][nh][m][i][2], acc[mh][nh][m][i][3]};
+              s2 += lo; s2 += hi;
+              q2 = __builtin_elementwise_fma(lo, lo, q2);
+              q2 = __builtin_elementwise_fma(hi, hi, q2);
+            }
+          float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
+          sm = xor16_sum(sm); sq = xor16_sum(sq);
+          sm = xor32_sum(sm); sq = xor32_sum(sq);
           if (fq == 0) part_lds[wc * 256 + mh * 128 + wr * 64 + m * 16 + fr] = make_float2(sm, sq);
         }
       __syncthreads();
