@@ -167,3 +167,22 @@ __device__ __forceinline__ f32x2_t gelu_erf_bf16out_x2(f32x2_t x) {
 // the ds_read_b128 operand reads of both the 16x16x32 and the 32x32x16 MFMA.
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Two pairs at once, statement by statement: the two dependent Horner chains interleave, so a v_pk_fma never
+// waits on the one just issued (the one-pair form left an s_nop after every packed op once the scheduler ran
+// out of independent work).  Same bits per element as gelu_erf_bf16out.
+__device__ __forceinline__ void gelu_erf_bf16out_x4(f32x2_t& a, f32x2_t& b) {
+  auto c = [](float v) { return (f32x2_t){v, v}; };
+  f32x2_t ac, bc;
+  ac[0] = __builtin_amdgcn_fmed3f(a[0], -3.9f, 3.9f); ac[1] = __builtin_amdgcn_fmed3f(a[1], -3.9f, 3.9f);
+  bc[0] = __builtin_amdgcn_fmed3f(b[0], -3.9f, 3.9f); bc[1] = __builtin_amdgcn_fmed3f(b[1], -3.9f, 3.9f);
+  const f32x2_t ua = ac * ac, ub = bc * bc;
+  f32x2_t qa = __builtin_elementwise_fma(c(2.627150074e-08f), ua, c(-1.770499288e-06f));
+  f32x2_t qb = __builtin_elementwise_fma(c(2.627150074e-08f), ub, c(-1.770499288e-06f));
+  qa = __builtin_elementwise_fma(qa, ua, c(5.123743311e-05f));  qb = __builtin_elementwise_fma(qb, ub, c(5.123743311e-05f));
+  qa = __builtin_elementwise_fma(qa, ua, c(-8.445144153e-04f)); qb = __builtin_elementwise_fma(qb, ub, c(-8.445144153e-04f));
+  qa = __builtin_elementwise_fma(qa, ua, c(8.913803536e-03f));  qb = __builtin_elementwise_fma(qb, ub, c(8.913803536e-03f));
+  qa = __builtin_elementwise_fma(qa, ua, c(-6.486952130e-02f)); qb = __builtin_elementwise_fma(qb, ub, c(-6.486952130e-02f));
+  qa = __builtin_elementwise_fma(qa, ua, c(3.980856433e-01f));  qb = __builtin_elementwise_fma(qb, ub, c(3.980856433e-01f));
+  a = a * __builtin_elementwise_fma(ac, qa, c(0.5f));
+  b = b * __builtin_elementwise_fma(bc, qb, c(0.5f));
+}

@@ -551,7 +551,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               float v2f = acc[mh][nh][m][i][2] + bv[nh][i][2], v3 = acc[mh][nh][m][i][3] + bv[nh][i][3];
               if (EPI == EPI_BIAS_GELU) {
                 // packed fp32 math: same bits per element as gelu_erf_bf16out, 296 -> 285 us on FFN-up
-                const f32x2_t g01 = gelu_erf_bf16out_x2((f32x2_t){v0, v1}), g23 = gelu_erf_bf16out_x2((f32x2_t){v2f, v3});
+                f32x2_t g01 = {v0, v1}, g23 = {v2f, v3};
+                gelu_erf_bf16out_x4(g01, g23);
                 v0 = g01[0]; v1 = g01[1]; v2f = g23[0]; v3 = g23[1];
               } else if (EPI == EPI_BIAS_TANH) {
                 v0 = tanhf(v0); v1 = tanhf(v1); v2f = tanhf(v2f); v3 = tanhf(v3);
