@@ -25,14 +25,25 @@ __device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
-                                                        int q_tiles) {
+                                                        int q_tiles, int n_heads, int n_pairs) {
   __shared__ __attribute__((aligned(16))) char k_lds[KT * 128];
   __shared__ __attribute__((aligned(16))) char v_lds[KT * 128];
 
-  const int seq = blockIdx.x / q_tiles, head = blockIdx.y;
+  int seq, head, qt;
+  if (n_pairs > 0) {
+    // q_tiles == 2, 1-D grid: the two q tiles of a (sequence, head) get workgroup ids 8 apart — the same XCD
+    // (ids go round-robin over the 8 XCDs), dispatched together, so the second one's K/V reads can hit that L2
+    const int id = blockIdx.x, pair = (id >> 4) * 8 + (id & 7);
+    if (pair >= n_pairs) return;
+    qt = (id >> 3) & 1;
+    seq = pair / n_heads;
+    head = pair - seq * n_heads;
+  } else {
+    seq = blockIdx.x / q_tiles; head = blockIdx.y; qt = blockIdx.x - seq * q_tiles;
+  }
   const int beg = cu[seq];
   const int len = cu[seq + 1] - beg;
-  const int q_tile0 = (blockIdx.x - seq * q_tiles) * 128;
+  const int q_tile0 = qt * 128;
   if (q_tile0 >= len) return;  // workgroup-uniform
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -384,7 +395,15 @@ hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, 
   if (n_seqs <= 0) return hipSuccess;
   if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;
   const int q_tiles = (max_seqlen + 127) / 128;
+#ifdef ATTN_PAIR
+  if (q_tiles == 2) {
+    const int n_pairs = n_seqs * n_heads;
+    hipLaunchKernelGGL(attention_kernel, dim3((n_pairs + 7) / 8 * 16), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
+                       q_tiles, n_heads, n_pairs);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL(attention_kernel, dim3(q_tiles * n_seqs, n_heads), dim3(256), 0, st, qkv,
-                     cu_seqlens, ctx, hidden, q_tiles);
+                     cu_seqlens, ctx, hidden, q_tiles, n_heads, 0);
   return hipGetLastError();
 }
