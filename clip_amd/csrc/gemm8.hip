@@ -656,13 +656,17 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
   if (e0 != hipSuccess) return e0;
   const int tiles_m = g.M / BM, tiles_n = g.N / BN, n_tiles = tiles_m * tiles_n;
   const int grid = n_cu < ((n_tiles + 7) & ~7) ? n_cu : ((n_tiles + 7) & ~7);
-  // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream
+  // column-tile group whose W slice (group_n x 256 rows x K) fits an XCD's L2 beside the A stream.  Round 2
+  // sweep (M = 130 560): slices of 1.2 / 1.6 / 2.4 / 3.5 MB run in the same time (QKV 380-382 us, FFN-up 544 us;
+  // 0.8 MB and the whole 4.7 MB FFN-up weight are 1-7 % slower), so the largest that fits is taken: the A panel
+  // is then fetched once (QKV) or twice (FFN-up) instead of 3 times
   int group_n = 0;
   if (tiles_m >= 8) {
     group_n = tiles_n;
-    if ((long)tiles_n * BN * g.K * 2 > 1700000 && g.K < 2048)
+    static const long group_bytes = getenv("GEMM8_GROUP_BYTES") ? atol(getenv("GEMM8_GROUP_BYTES")) : 3600000;  // diagnostic override
+    if ((long)tiles_n * BN * g.K * 2 > group_bytes && g.K < 2048)
       for (int d = 1; d <= tiles_n; ++d)
-        if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= 1700000) group_n = d;
+        if (tiles_n % d == 0 && (long)d * BN * g.K * 2 <= group_bytes) group_n = d;
   }
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), LDS8, st, static_cast<const bf16_t*>(g.A),
                      static_cast<const bf16_t*>(g.W), g.bias, g.res, g.out, g.K,
