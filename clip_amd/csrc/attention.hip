@@ -22,6 +22,23 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int swz_v(int row, int chunk) { return chunk ^ (((row >> 1) & 1) << 2); }
 
+// diagnostic builds (-DATTN_STAMPS, tools/attn_stamps.py): wave 0 of the first 4096 workgroups stamps its life
+// (s_memtime): 0 entry, 1 loop entry, 2..7 the sections of key tile 1 (top, tiles stored + barriers, next loads
+// issued, S MFMAs, softmax, PV MFMAs), 8 loop exit, 9 outputs stored
+#ifdef ATTN_STAMPS
+__device__ uint32_t g_attn_stamps[4096 * 16];
+#define A_STAMP(k)                                                               \
+  if (tid == 0 && lin_id < 4096) {                                               \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    g_attn_stamps[lin_id * 16 + (k)] = (uint32_t)__builtin_readcyclecounter();   \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  }
+#define A_STAMP_T(k) if (t == 1) { A_STAMP(k) }
+#else
+#define A_STAMP(k)
+#define A_STAMP_T(k)
+#endif
+
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
@@ -47,6 +64,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   if (q_tile0 >= len) return;  // workgroup-uniform
 
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ATTN_STAMPS
+  const int lin_id = blockIdx.y * gridDim.x + blockIdx.x;
+#endif
+  A_STAMP(0)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int ld = 3 * hidden;  // qkv row stride (elements)
@@ -100,11 +121,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
   const int n_tiles = (len + KT - 1) / KT;
   load_tile(0);
+  A_STAMP(1)
   for (int t = 0; t < n_tiles; ++t) {
+    A_STAMP_T(2)
     __syncthreads();  // previous tile's LDS reads done
     store_tile();
     __syncthreads();
+    A_STAMP_T(3)
     if (t + 1 < n_tiles) load_tile((t + 1) * KT);
+    A_STAMP_T(4)
     if (!wave_live) continue;
 
     const int kv0 = t * KT;
@@ -125,6 +150,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         }
       }
     }
+    A_STAMP_T(5)
     // ---- keys past the end exist only in the last tile (wave-uniform test): mask there only
     if (kv0 + KT > len) {
 #pragma unroll
@@ -155,6 +181,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     // ---- P = exp2(S - m), O^T += V^T P^T
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 0) { A_STAMP_T(6) }
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -189,8 +216,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         }
       }
     }
+    A_STAMP_T(7)
   }
 
+  A_STAMP(8)
   if (!wave_live) return;
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
@@ -207,7 +236,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                        pack_op2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
       }
   }
+  A_STAMP(9)
 }
+}  // namespace
+#ifdef ATTN_STAMPS
+#if !CLIP_OPERAND_F16
+extern "C" int clip_debug_attn_stamps(uint32_t* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), (size_t)n_words * 4);
+}
+#endif
+#endif
+namespace {
 
 // Last-layer form: only the pooled token of each sequence is consumed downstream
 // (ref: sentclf/bert_model.py:52-58 gathers ONE hidden row per sentence; :234 uses row 0), so its
