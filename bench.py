@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows-per-step", type=int, default=510)
     ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
+                    help="operand type of the kernels (clip_set_precision); the headline metric is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
     args = ap.parse_args()
@@ -85,6 +87,7 @@ def main():
     tokens = args.rows_per_step * args.seq_len
     model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=tokens, max_seqs=args.rows_per_step)
     model.load_state_dict(sd)
+    model.set_precision(args.precision)
     model.to(device).eval()
     model.set_sep_token_id(102)
     model.set_n_context_sentences(n_ctx)
@@ -147,7 +150,7 @@ def main():
     # timed steps: the nameplate 2.5 PF assumes 2.4 GHz, which no board holds under a dense MFMA stream
     peak_best, peak_mean, peak_ms = C.c_double(0), C.c_double(0), C.c_double(0)
     if rank == 0:
-        _lib.check(lib.clip_mfma_peak(_lib.PRECISION_BF16, 12000, 5, C.byref(peak_best), C.byref(peak_mean),
+        _lib.check(lib.clip_mfma_peak(_lib.PRECISION_F16 if args.precision == "f16" else _lib.PRECISION_BF16, 12000, 5, C.byref(peak_best), C.byref(peak_mean),
                                       C.byref(peak_ms)))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
@@ -191,10 +194,10 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         res = {
-            "metric": "sentences/sec scored (whole node) BERT-base+Context seq256 bf16",
+            "metric": "sentences/sec scored (whole node) BERT-base+Context seq256 " + args.precision,
             "value": round(value, 2), "unit": "sentences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic token ids (uniform in [1000, vocab)), procedural N(0,0.02) weights",
             "config": {"workload": f"C3 BERT-base+Context n_ctx=2, fixed L={args.seq_len}, "
                                    f"{args.rows_per_step} rows ({T} tokens) per step per GPU",
