@@ -72,7 +72,7 @@ def _logits(cfg, sd, rows, n_ctx, precision, batch_size):
 # equally; tools/rounding_study.py with OPERAND=f16); bf16 5.1e-2 (6.2e-2 absolute: 2.5x OVER the budget).
 # The asserts below are those measurements with 20 % head-room — regression guards, not a claim that the
 # 2e-2 budget holds for 16-bit operands on logits of +-8; the thresholded-label agreement above is the
-# criterion that is met (f16 >= 99.97 %, bf16 99.87-99.93 % on these weights).
+# criterion that is met by f16 (>= 99.97 %); bf16 reaches 99.79-99.93 % on these weights.
 BAND = 2.5
 
 
@@ -95,9 +95,11 @@ def test_thresholded_label_agreement_at_scale(kind, weights, precision):
         if not (weights == "trained_like" and precision == "bf16"):
             assert agree >= 0.999
         else:
-            # bf16 operands on trained-like weights: measured 99.89-99.93 %, at the bar, not reliably above
-            # it — the setting for such checkpoints is f16 (asserted above); this guards against regressions
-            assert agree >= 0.998
+            # bf16 operands on trained-like weights: measured 99.79-99.93 % (tools/agreement_ab.py: three row
+            # seeds x two library builds with the same rms logit error, 19-60 of 28672 decisions differ) —
+            # BELOW the 99.9 % bar on the ttp thresholds; the setting for such checkpoints is f16 (asserted
+            # above).  This line only guards against regressions.
+            assert agree >= 0.997
 
 
 @pytest.mark.parametrize("name", ["base_ctx_stress", "base_sent_stress"])
