@@ -53,7 +53,65 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(int iters, float* __rest
   if (s == 1.2345e-30f) sink[id] = s;  // keeps the loop alive; never true
 }
 
+// the same loop on v_mfma_f32_32x32x16_bf16 (half the operand-register reads per flop): 4 chains of 16 registers
+__global__ __launch_bounds__(512) void mfma_peak32_kernel(int iters, float* __restrict__ sink) {
+  const uint32_t id = blockIdx.x * 512 + threadIdx.x;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (mix(id * 8 + i + 1) & 0x807f807fu) | 0x3f803f80u;
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const pk_bf16x8_t a = *reinterpret_cast<const pk_bf16x8_t*>(&w[0]);
+        const pk_bf16x8_t b = *reinterpret_cast<const pk_bf16x8_t*>(&w[4]);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r ? b : a, r ? a : b, acc[i], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 1.2345e-30f) sink[id] = s;
+}
+
 }  // namespace
+
+// diagnostic: the 32x32x16 shape (8 MFMAs of 32768 flops per iteration and wave); tools/peak_shapes.py
+extern "C" int clip_debug_mfma_peak32(int32_t iters, int32_t repeats, double* tflops_mean, double* ms_mean) {
+  int dev = 0, cus = 0;
+  if (!tflops_mean || !ms_mean || iters < 1 || repeats < 1) return CLIP_ERR_ARG;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return CLIP_ERR_HIP;
+  float* sink = nullptr;
+  if (hipMalloc(&sink, (size_t)cus * 512 * 4) != hipSuccess) return CLIP_ERR_HIP;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  double sum_ms = 0.0;
+  int rc = CLIP_OK;
+  for (int r = 0; r < repeats + 1; ++r) {
+    (void)hipEventRecord(a, nullptr);
+    hipLaunchKernelGGL(mfma_peak32_kernel, dim3(cus), dim3(512), 0, nullptr, iters, sink);
+    (void)hipEventRecord(b, nullptr);
+    if (hipEventSynchronize(b) != hipSuccess) { rc = CLIP_ERR_HIP; break; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (r) sum_ms += ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(sink);
+  *ms_mean = sum_ms / repeats;
+  *tflops_mean = (double)cus * 8 * iters * 8 * (2.0 * 32 * 32 * 16) / (*ms_mean * 1e-3) / 1e12;
+  return rc;
+}
 
 extern "C" int clip_mfma_peak(int32_t operand, int32_t iters, int32_t repeats, double* tflops_best,
                               double* tflops_mean, double* ms_mean) {
