@@ -34,7 +34,7 @@ from .fast_tokenizer import FastWordPiece, build_rows_chunks, build_rows_fast
 from .config import BertConfig
 from .constants import LABEL_TYPES
 from .datasets import SentDataset, SentEvalDataset
-from .columnar import ColumnarCorpus, chunk_bounds, save_rows
+from .columnar import ColumnarCorpus, graded_chunk_bounds, save_rows
 from .job import RunningTopK, write_topk_csv
 from .scoring import BulkScorer, PackedRows, write_ttp_csv
 
@@ -62,6 +62,15 @@ def main(argv=None):
                         help="ranks to start, one per MI355X (documents are sharded; ignored under torchrun)")
     parser.add_argument("--tokenize_only", action="store_true", help="stop after --save_rows (needs no GPU)")
     args = parser.parse_args(argv)
+    import sys
+    import time
+    t_start = time.perf_counter()
+    timing = os.environ.get("CLIP_AMD_TIMING") == "1"      # stage times on stderr (tools/cli_bench.py)
+
+    def stamp(what):
+        if timing:
+            print(f"[clip_amd timing] {time.perf_counter() - t_start:7.3f} s  {what}", file=sys.stderr, flush=True)
+
     if args.task != "multilabel":
         raise NotImplementedError("only --task multilabel is on the accelerated path")
 
@@ -86,11 +95,14 @@ def main(argv=None):
             sd = load_file(args.local_weights)
         else:
             sd = torch.load(args.local_weights, map_location="cpu", weights_only=True)       # :78
+        stamp("weights file read")
         model.load_state_dict(sd)                                                          # :79
         model.set_precision(args.precision)
         model.to(device).eval()                                                            # :72,100
+        stamp("state dict loaded")
         with torch.cuda.device(device):
             model._ensure_engine()
+        stamp("engine ready")
         return model
 
     pool = ThreadPoolExecutor(max_workers=3)
@@ -115,14 +127,15 @@ def main(argv=None):
             else:
                 dataset = SentEvalDataset(args.unlabeled_fname, args.task,
                                           n_context_sentences=args.n_context_sentences)
+            stamp(f"CSV read ({len(dataset)} rows)")
             meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=tokenizer.sep_token_id,
                         cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
                         source=os.path.basename(args.unlabeled_fname))
             if world == 1 and not args.tokenize_only:
                 # one rank: tokenise in pieces of whole documents on a helper thread WHILE the GPU scores the
                 # piece before (any chunking gives the same files: parts are concatenated in order and the
-                # top-k is a running merge)
-                stream = (dataset, tokenizer, chunk_bounds(dataset.doc_ids, min(args.chunk_rows, 100_000)), meta)
+                # top-k is a running merge); the first pieces are small so that the GPU starts early
+                stream = (dataset, tokenizer, graded_chunk_bounds(dataset.doc_ids, min(args.chunk_rows, 131_072)), meta)
             else:
                 rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
                 if corpus_dir:
@@ -188,19 +201,30 @@ def main(argv=None):
 
     n_chunks = len(stream[2]) if stream is not None else len(corpus.chunk_bounds(args.chunk_rows))
     top = RunningTopK(args.topk) if args.topk > 0 else None
-    n_rows = n_kept = 0
+    counts = [0, 0]          # rows, kept
     res = None
     writes = []
-    for c, rows_c, d_c, s_c in chunk_source():
-        res = scorer.score(rows_c, d_c, s_c)
-        writes.append(pool.submit(write_ttp_csv, f"{out}.chunk{c}", res))      # formatted while the next chunk is scored
+    post = ThreadPoolExecutor(max_workers=1)       # per-chunk host work, in chunk order, off the scoring thread
+
+    def fold(r):
         if top is not None:
-            top.update(res.doc_ids, res.sent_ixs, res.max_score, keep=res.keep)
-        n_rows += len(res.keep)
-        n_kept += int(res.keep.sum())
+            top.update(r.doc_ids, r.sent_ixs, r.max_score, keep=r.keep)
+        counts[0] += len(r.keep)
+        counts[1] += int(r.keep.sum())
+
+    for c, rows_c, d_c, s_c in chunk_source():
+        stamp(f"chunk {c} tokenised ({len(d_c)} rows)")
+        res = scorer.score(rows_c, d_c, s_c)
+        stamp(f"chunk {c} scored")
+        # formatted / folded into the running top-k while the next chunk is scored
+        writes.append(pool.submit(write_ttp_csv, f"{out}.chunk{c}", res))
+        writes.append(post.submit(fold, res))
     for w in writes:
         w.result()
     pool.shutdown()
+    post.shutdown()
+    n_rows, n_kept = counts
+    stamp("CSV parts written")
     if dist is not None:
         dist.barrier()
     if rank == 0:                                       # parts in chunk order = input order (:97-98,124)
@@ -217,6 +241,7 @@ def main(argv=None):
                        device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tot)                            # counts over all ranks
+    stamp("files complete")
     if rank == 0:
         print(f"done! results in {out_dir}  ({int(tot[0])} of {int(tot[1])} sentences selected, {world} rank(s))")
     if dist is not None:

@@ -59,6 +59,22 @@ def chunk_bounds(doc_ids, chunk_rows):
     return bounds
 
 
+def graded_chunk_bounds(doc_ids, chunk_rows, first_rows=16384):
+    """chunk_bounds whose first pieces are small and double up to chunk_rows: a pipelined consumer (the GPU)
+    starts after first_rows rows are ready instead of chunk_rows.  Any chunking gives the same output files."""
+    fine = chunk_bounds(doc_ids, min(first_rows, chunk_rows))
+    out, want, i = [], min(first_rows, chunk_rows), 0
+    while i < len(fine):
+        a, b = fine[i]
+        i += 1
+        while i < len(fine) and fine[i][1] - a <= want:
+            b = fine[i][1]
+            i += 1
+        out.append((a, b))
+        want = min(chunk_rows, want * 2)
+    return out
+
+
 class ColumnarCorpus:
     @classmethod
     def from_arrays(cls, rows: PackedRows, doc_ids, sent_ixs, **meta):

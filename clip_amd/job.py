@@ -14,7 +14,6 @@ index) only, so the global top-k is the same for every world size — the proper
 tests/test_gpu_job.py checks.
 """
 import argparse
-import csv
 import json
 import os
 import time
@@ -77,11 +76,10 @@ def run_rank(scorer, config, n_rows, chunk_rows_n, k, rank, world, vocab_size, o
 def write_topk_csv(path, records):
     """The focus file of task-targeted pre-training: header doc_id,sent_ix as
     sentclf/pretrain_tasks.py:37,57-58 reads it, score last."""
-    with open(path, "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["doc_id", "sent_ix", "max_label_score"])
-        for r in records:
-            w.writerow([r["doc_id"], r["sent_ix"], r["score"]])
+    from .scoring import format_score_rows
+    with open(path, "w", newline="") as f:      # csv.writer's bytes (header, '\r\n' row ends), formatted by arrays
+        f.write("doc_id,sent_ix,max_label_score\r\n")
+        f.write(format_score_rows(records["doc_id"], records["sent_ix"], records["score"]))
 
 
 def main(argv=None):

@@ -143,7 +143,8 @@ class BulkScorer:
         thr = None if self.label_threshs is None else torch.tensor(self.label_threshs, dtype=torch.float64, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         n_ctx_arg = self.n_ctx if self.n_ctx > 0 else -1
-        flat_s, off_s = rows.gather_all(order)          # the chunk in step order, gathered once
+        lens_s = rows.lens[order].astype(np.int64)      # the chunk in step order
+        start_s = rows.offsets[order]
 
         with torch.cuda.device(dev):
             stream = _lib.stream_ptr()
@@ -151,13 +152,18 @@ class BulkScorer:
             w = self._workspace(dev, L)
             ids_d, cu_d, tt_d, pos_d, focus_d, logits = (w[k] for k in ("ids", "cu", "tt", "pos", "focus", "logits"))
             for k, (a, b) in enumerate(steps):
-                n, t0 = b - a, int(off_s[a])
-                T = int(off_s[b]) - t0
+                n = b - a
                 # two pinned staging buffers, reused: wait for the copy that last read this one
                 ids_h, cu_h, ids_hn, cu_hn, ev = w["stage"][k & 1]
                 ev.synchronize()
-                ids_hn[:T] = flat_s[t0:t0 + T]
-                np.subtract(off_s[a:b + 1], t0, out=cu_hn[:n + 1], casting="unsafe")
+                # this step's rows gathered straight into the staging buffer, while the GPU runs the steps
+                # queued before (token t of row i comes from start[i] + (t - cu[i]))
+                cu_hn[0] = 0
+                np.cumsum(lens_s[a:b], out=cu_hn[1:n + 1])
+                T = int(cu_hn[n])
+                src = np.repeat(start_s[a:b] - cu_hn[:n], lens_s[a:b])
+                src += np.arange(T)
+                np.take(rows.flat, src, out=ids_hn[:T])
                 ids_d[:T].copy_(ids_h[:T], non_blocking=True)
                 cu_d[:n + 1].copy_(cu_h[:n + 1], non_blocking=True)
                 ev.record()
@@ -196,12 +202,18 @@ def write_ttp_csv(path, result: ScoreResult):
     # quoting), built with array operations: numpy's float32 -> str is the same shortest-repr text
     sel = np.nonzero(result.keep)[0]
     with open(path, "w", newline="") as f:
-        if len(sel):
-            d = result.doc_ids[sel].astype(str)
-            s = np.asarray(result.sent_ixs)[sel].astype(str)
-            m = np.asarray(result.max_score, np.float32)[sel].astype(str)
-            lines = np.char.add(np.char.add(np.char.add(np.char.add(d, ","), s), ","), m)
-            f.write("\r\n".join(lines.tolist()) + "\r\n")
+        f.write(format_score_rows(result.doc_ids[sel], np.asarray(result.sent_ixs)[sel], result.max_score[sel]))
+
+
+def format_score_rows(doc_ids, sent_ixs, scores):
+    """csv.writer's text for rows [int doc_id, int sent_ix, np.float32 score], as one string."""
+    if len(doc_ids) == 0:
+        return ""
+    d = np.asarray(doc_ids).astype(str)
+    s = np.asarray(sent_ixs).astype(str)
+    m = np.asarray(scores, np.float32).astype(str)
+    lines = np.char.add(np.char.add(np.char.add(np.char.add(d, ","), s), ","), m)
+    return "\r\n".join(lines.tolist()) + "\r\n"
 
 
 def read_ttp_csv(path):

@@ -52,3 +52,15 @@ def test_one_long_document_and_bad_directory(tmp_path):
         columnar.ColumnarCorpus(str(tmp_path / "c"))
     with pytest.raises(ValueError):
         columnar.save_rows(str(tmp_path / "d"), rows, d[:-1], s)
+
+
+def test_graded_chunk_bounds():
+    _, d, _ = _corpus(20000, seed=9)
+    b = columnar.graded_chunk_bounds(d, 4096, first_rows=256)
+    assert b[0][0] == 0 and b[-1][1] == len(d)
+    assert all(a1 == b0 for (_, b0), (a1, _) in zip(b, b[1:]))                       # a partition
+    assert all(e == len(d) or d[e] != d[e - 1] for _, e in b)                        # whole documents
+    sizes = [e - a for a, e in b]
+    assert sizes[0] <= 256 and max(sizes) <= 4096 and max(sizes) > 2048              # small first, grows to chunk_rows
+    assert columnar.graded_chunk_bounds(d, 100, first_rows=256) == columnar.chunk_bounds(d, 100)
+    assert columnar.graded_chunk_bounds(d[:0], 100) == []

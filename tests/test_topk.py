@@ -96,3 +96,25 @@ def test_global_topk_over_gloo_world2(tmp_path):
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npy")
         assert np.array_equal(got, ref)          # bit-exact, identical on every rank
+
+
+def test_write_topk_csv_is_csv_writer_bytes(tmp_path):
+    """the focus file (pretrain_tasks.py:37,57-58 reads doc_id / sent_ix columns): same bytes as csv.writer
+    over [doc_id, sent_ix, np.float32 score] rows"""
+    import csv
+    from clip_amd.job import write_topk_csv
+    rng = np.random.default_rng(3)
+    rec = np.empty(2000, topk.RECORD)
+    rec["doc_id"] = rng.integers(-5, 10**12, 2000)
+    rec["sent_ix"] = rng.integers(0, 4000, 2000)
+    rec["score"] = np.concatenate((rng.random(1990, dtype=np.float32),
+                                   np.asarray([0, 1, 1e-8, 0.5, 0.1, 0.30000001, 1e-45, 0.999999, 3e-5, 0.05], np.float32)))
+    write_topk_csv(str(tmp_path / "a.csv"), rec)
+    with open(tmp_path / "b.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["doc_id", "sent_ix", "max_label_score"])
+        for r in rec:
+            w.writerow([r["doc_id"], r["sent_ix"], r["score"]])
+    assert (tmp_path / "a.csv").read_bytes() == (tmp_path / "b.csv").read_bytes()
+    write_topk_csv(str(tmp_path / "e.csv"), rec[:0])
+    assert (tmp_path / "e.csv").read_bytes() == b"doc_id,sent_ix,max_label_score\r\n"
