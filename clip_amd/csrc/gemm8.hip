@@ -260,10 +260,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         if (v1) {
           stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
           if (GEMM8_SPLIT == 0) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+#ifdef GEMM8_EXTRA_DMA  // experiment: 1.5x the DMA pieces per MFMA (the same half-tile staged twice: identical bytes)
+          stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#else
           // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
           // (t).A1, read next phase, is older
           if (GEMM8_SPLIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -306,10 +311,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         if (v2) {
           stage_half(a2, a_off, lda, B * 4 + 0);
           if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ldw, B * 4 + 1);
+#ifdef GEMM8_EXTRA_DMA
+          stage_half(w2, w_off, ldw, B * 4 + 1);
+#endif
         }
         advance();
         if (staged2) {
+#ifdef GEMM8_EXTRA_DMA
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
