@@ -38,6 +38,8 @@ shapes = [("qkv", 2304, 768, 0, False), ("attn_out", 768, 768, 4, True), ("ffn_u
 if os.environ.get("SHAPES") == "ln":    # fused LayerNorm (epi 5) against GEMM + residual recompute (epi 4; + a 46 us LayerNorm kernel)
     shapes = [("attn_out lnres", 768, 768, 4, True), ("attn_out lnout", 768, 768, 5, False),
               ("ffn_down lnres", 768, 3072, 4, True), ("ffn_down lnout", 768, 3072, 5, False)]
+if os.environ.get("SHAPES") == "bf16out":   # the two shapes gemm9.hip (tile 3) takes
+    shapes = [("qkv", 2304, 768, 0, False), ("ffn_up", 3072, 768, 1, False)]
 if os.environ.get("SHAPES") == "res":   # what does the residual read cost the fp32-output GEMMs?
     shapes = [("attn_out nores", 768, 768, 0, True), ("attn_out bf16res", 768, 768, 2, True), ("attn_out lnres", 768, 768, 4, True),
               ("ffn_down nores", 768, 3072, 0, True), ("ffn_down bf16res", 768, 3072, 2, True), ("ffn_down lnres", 768, 3072, 4, True),
