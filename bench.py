@@ -167,6 +167,23 @@ def main():
     glob = topk.global_topk(local, 64)
     topk_ms = (time.perf_counter() - t_k) * 1e3
 
+    # the same stage at configuration C4's size (BASELINE.json configs[3]: global top-250k): 400 k synthetic
+    # records per rank with many tied scores -> local top-250k -> ONE all-gather of 250 001 16-byte records per
+    # rank (4 MB each: RCCL over xGMI when N GPUs are visible) -> the same merge on every rank; rank 0 checks
+    # the result against one sort over every rank's records.
+    K4, N4 = 250_000, 400_000
+
+    def c4_records(r):
+        g4 = np.random.default_rng(4242 + r)
+        return (r * 10_000_000 + np.arange(N4, dtype=np.int64) // 40, np.arange(N4, dtype=np.int64) % 40,
+                np.round(g4.random(N4, dtype=np.float32), 3).astype(np.float32))       # ~1000 distinct scores: ties
+    d4, s4, m4 = c4_records(rank)
+    if dist is not None:
+        dist.barrier()
+    t_k = time.perf_counter()
+    glob4 = topk.global_topk(topk.local_topk(d4, s4, m4, K4), K4)
+    topk4_ms = (time.perf_counter() - t_k) * 1e3
+
     if rank == 0:
         rows_total = world * args.rows_per_step * args.steps
         value = rows_total / elapsed
@@ -226,6 +243,14 @@ def main():
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else None),
                        "gpus_visible": torch.cuda.device_count()}
         res["topk"] = {"k": 64, "records": int(len(glob)), "ms_local_select_allgather_merge": round(topk_ms, 3)}
+        every = [c4_records(r) for r in range(world)]
+        want4 = topk.local_topk(np.concatenate([e[0] for e in every]), np.concatenate([e[1] for e in every]),
+                                np.concatenate([e[2] for e in every]), K4)
+        res["topk_c4"] = {"k": K4, "records_per_rank": N4, "allgather_bytes_per_rank": (K4 + 1) * 16,
+                          "ms_local_select_allgather_merge": round(topk4_ms, 1),
+                          "equals_one_sort_over_all_records": bool(glob4.tobytes() == want4.tobytes())}
+        if not res["topk_c4"]["equals_one_sort_over_all_records"]:
+            raise RuntimeError("global top-k over %d rank(s) differs from one sort over all records" % world)
         if args.breakdown:
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
         if world == 1 and not args.no_cpu_baseline:

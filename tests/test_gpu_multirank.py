@@ -35,6 +35,9 @@ def test_bench_gpus_2_starts_two_ranks():
     assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2
     assert line["dist"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
     assert line["value"] > 0 and line["scaling"] == "weak"
+    # the end-of-job stage at configuration C4's size: one all-gather of 250 001 records per rank, checked in
+    # bench.py itself against one sort over both ranks' records
+    assert line["topk_c4"]["k"] == 250000 and line["topk_c4"]["equals_one_sort_over_all_records"] is True
     # whole-job value = rows of BOTH ranks over the slowest rank's time
     assert abs(line["value"] - 2 * 85 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 1e-3
 
