@@ -103,7 +103,7 @@ class BulkScorer:
         self._ws = None
 
     def _workspace(self, dev, L):
-        """Per-scorer step buffers, allocated ONCE (the step loop allocates and pins nothing): device
+        """Per-scorer step buffers, allocated ONCE (the step loop makes no device or pinned-host allocation; its only temporaries are the numpy index arrays of the per-step gather): device
         tensors for one step (steps are serialised on the stream) and two pinned host staging buffers."""
         if self._ws is not None and self._ws["dev"] == dev:
             return self._ws
