@@ -537,8 +537,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
                   make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
             }
+#ifndef LNOUT_NO_XRES_STORE   // timing experiment: one output copy only
             out_store(*reinterpret_cast<const u32x4_t*>(&hv),
                       reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
+#endif
           }
 #pragma unroll
           for (int p = 0; p < 2; ++p) {

@@ -68,7 +68,7 @@ for sname, N, K, epi, f32 in shapes:
     def run(v):
         if epi == 5:
             epoch[0] += 1
-            rc = libs[v[0]].clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(xres), 1, _lib.ptr(gamma),
+            rc = libs[v[0]].clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(xres), int(os.environ.get("RES_TILED", "1")), _lib.ptr(gamma),
                                                  _lib.ptr(beta), 1e-12, _lib.ptr(out), _lib.ptr(xres), _lib.ptr(part),
                                                  _lib.ptr(flags), epoch[0], _lib.ptr(errw), M, N, K, K, K, N, N,
                                                  _lib.stream_ptr())
