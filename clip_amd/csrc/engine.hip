@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -290,12 +291,16 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
   // rewrites); the very first residual is the embedding LayerNorm's row-major copy
   bool first_res = true;
+  // f16 setting: operand copy and residual copy would hold the same fp16 bits, so there is ONE: x, row-major,
+  // read as the residual and rewritten in place by the fused GEMMs (no xres / xres_rm traffic at all)
+  constexpr bool single = std::is_same<KS, k_f16>::value;
   auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
                      const float* beta) {
-    GemmArgs a{A, W, bias, first_res ? e->xres_rm : e->xres, e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
+    GemmArgs a{A, W, bias, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres), e->x, M, H, K,
+               K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta;
-    a.lnout = LnOutArgs{e->xres, !first_res, e->lnpart, e->lnflags, ++e->epoch, c.layer_norm_eps, e->dev_err,
-                        e->test_drop ? 1u : 0u};
+    a.lnout = LnOutArgs{single ? nullptr : e->xres, !single && !first_res, e->lnpart, e->lnflags, ++e->epoch,
+                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u};
     first_res = false;
     return KS::launch_gemm(a, st);
   };
@@ -311,7 +316,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(KS::launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
                             c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
-                            (f32 || fused) ? nullptr : e->stats[0], fused ? e->xres_rm : nullptr));
+                            (f32 || fused) ? nullptr : e->stats[0], fused && !single ? e->xres_rm : nullptr));
   }
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
@@ -401,10 +406,10 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
       if (fused) {
         // (a one-layer model trims its only layer: the residual is still the embedding's row-major copy)
-        GemmArgs a{e->ctx_rows, L.wo, L.bo, first_res ? e->xres_rm : e->xres, e->pre_rows[0], n_seqs, H, H, H, H, H, H,
-                   EPI_BIAS_RES16, true};
+        GemmArgs a{e->ctx_rows, L.wo, L.bo, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres),
+                   e->pre_rows[0], n_seqs, H, H, H, H, H, H, EPI_BIAS_RES16, true};
         a.res_index = focus;
-        a.res_tiles_n = first_res ? 0 : H / 256;
+        a.res_tiles_n = (single || first_res) ? 0 : H / 256;
         HIP_TRY(KS::launch_gemm(a, st));
       } else {
         HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));

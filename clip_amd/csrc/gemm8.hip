@@ -90,7 +90,11 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int EPI, bool OUT_F32, bool RES_TILED = false>
+// SINGLE (EPI_BIAS_LNOUT, fp16 operands only): the LayerNorm output is written ONCE, row-major, and serves as the
+// next GEMM's operand AND as the next residual (in the f16 setting the two copies of the bf16 setting hold the
+// same bits); the residual is then read from the row-major buffer this tile rewrites in place (every wave reads
+// exactly the 64 x 64 blocks it writes).
+template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int K, int lda, int ldw, int ldo,
@@ -399,12 +403,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
             }
         }
       } else {
-        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
+        // SINGLE: the residual IS the output buffer's current content (read through `out`, not through the
+        // second restrict-qualified pointer); these loads come before the barriers of the exchange, the stores after
+        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(SINGLE ? static_cast<const void*>(out) : resv);
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
+            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * (SINGLE ? ldo : ldres);
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       // (5) normalise in registers; the fp16 residual copy goes out tiled straight from the registers
       // (1-KiB wave stores), the bf16 GEMM operand through the transpose scratch as whole row segments
       const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + fq * 4;
-      uint16_t* xt = lo.xres_out + xt_base;
+      uint16_t* xt = SINGLE ? nullptr : lo.xres_out + xt_base;
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -538,8 +544,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                   make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
             }
 #ifndef LNOUT_NO_XRES_STORE   // timing experiment: one output copy only
-            out_store(*reinterpret_cast<const u32x4_t*>(&hv),
-                      reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
+            if (!SINGLE)
+              out_store(*reinterpret_cast<const u32x4_t*>(&hv),
+                        reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
 #endif
           }
 #pragma unroll
@@ -648,9 +655,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32, bool RES_TILED = false>
+template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false>
 hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
-  auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED>;
+  auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED, SINGLE>;
   static DeviceOnce once;  // per instantiation and device: function attribute + workgroup count
   int n_cu = 0;
   hipError_t e0 = once.get([&](int dev, int* val) {
@@ -702,8 +709,16 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
     case EPI_BIAS_LNRES * 2 + 1: return launch_8<EPI_BIAS_LNRES, true>(g, st);
     case EPI_BIAS_LNOUT * 2 + 0:
-      if (g.N / BN > 8 || !g.lnout.xres_out || !g.lnout.part || !g.lnout.flags || !g.lnout.err || !g.res)
-        return hipErrorInvalidValue;
+      if (g.N / BN > 8 || !g.lnout.part || !g.lnout.flags || !g.lnout.err || !g.res) return hipErrorInvalidValue;
+      if (!g.lnout.xres_out) {
+#if CLIP_OPERAND_F16
+        // one copy: operand = residual (fp16), read row-major from the buffer the tile rewrites
+        if (g.lnout.res_tiled || g.res != g.out || g.ldres != g.ldo) return hipErrorInvalidValue;
+        return launch_8<EPI_BIAS_LNOUT, false, false, true>(g, st);
+#else
+        return hipErrorInvalidValue;   // bf16 operands need the separate fp16 residual copy
+#endif
+      }
       return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true>(g, st) : launch_8<EPI_BIAS_LNOUT, false, false>(g, st);
     default: return hipErrorInvalidValue;
   }
