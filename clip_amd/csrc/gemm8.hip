@@ -402,15 +402,49 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                   acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[i * 4 + e];
             }
         }
+      } else if (SINGLE) {
+        // The residual IS the output buffer's current content (read through `out`, not through the second
+        // restrict-qualified pointer); these loads come before the barriers of the exchange, the stores after.
+        // Whole 128-byte row segments (16 B per lane, 8 rows per instruction) through this wave's transpose
+        // scratch, read back in accumulator layout — the output path backwards; 4 blocks (8 loads) in flight.
+        const uint16_t* xr = reinterpret_cast<const uint16_t*>(out);
+        const int lrow = lane >> 3, c16 = lane & 7;
+        const uint16_t* xr0 = xr + ((size_t)tm * BM + wr * 64 + lrow) * ldo + n_base + c16 * 8;
+        char* scw = scr + lrow * 128 + ((c16 ^ (lrow & 7)) * 16);   // (row + 8) & 7 == row & 7: + 1024 for p = 1
+#pragma unroll
+        for (int mb = 0; mb < 8; mb += 2) {   // two 16-row blocks (4 loads) in flight
+          __builtin_amdgcn_sched_barrier(0);
+          uint4 rv[2][2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int mh = (mb + k) >> 2, m = (mb + k) & 3;
+              rv[k][p] = *reinterpret_cast<const uint4*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo);
+            }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int mh = (mb + k) >> 2, m = (mb + k) & 3;
+            *reinterpret_cast<uint4*>(scw) = rv[k][0];
+            *reinterpret_cast<uint4*>(scw + 1024) = rv[k][1];
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
+                const f16x4_t r = *reinterpret_cast<const f16x4_t*>(scr + fr * 128 + sl * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[e];
+              }
+          }
+        }
       } else {
-        // SINGLE: the residual IS the output buffer's current content (read through `out`, not through the
-        // second restrict-qualified pointer); these loads come before the barriers of the exchange, the stores after
-        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(SINGLE ? static_cast<const void*>(out) : resv);
+        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * (SINGLE ? ldo : ldres);
+            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
