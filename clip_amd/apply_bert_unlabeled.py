@@ -22,6 +22,7 @@ all-gather.
 import argparse
 import os
 import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -173,26 +174,40 @@ def main(argv=None):
             return
         dataset, tokenizer, bounds, meta = stream
         q = queue.Queue(maxsize=2)
+        stop = threading.Event()        # the consumer gave up (an exception in scoring): the producer must not block forever
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 for c, item in enumerate(build_rows_chunks(dataset, tokenizer, args.n_context_sentences, bounds)):
-                    q.put((c,) + item)
-                q.put(None)
+                    if not put((c,) + item):
+                        return
+                put(None)
             except BaseException as exc:      # surfaces in the consumer
-                q.put(exc)
+                put(exc)
 
         pool.submit(produce)
         kept = []
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            if args.save_rows:
-                kept.append(item[1:])
-            yield item
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                if args.save_rows:
+                    kept.append(item[1:])
+                yield item
+        finally:
+            stop.set()
         if args.save_rows:
             lens = np.concatenate([k[0].lens for k in kept]) if kept else np.zeros(0, np.int64)
             rows = PackedRows(np.concatenate([k[0].flat for k in kept]) if kept else np.zeros(0, np.int32),

@@ -147,3 +147,38 @@ def test_cli_scores_every_row_including_trimmed_and_backfilled(tmp_path):
                 assert abs(float(got[k][2]) - float(score[j])) < 2e-3, (k, got[k], score[j])
                 k += 1
     assert n_long >= 1 and n_backfilled >= 1      # the fixture does exercise those branches
+
+
+def test_cli_failure_in_scoring_ends_the_job(tmp_path, monkeypatch):
+    """An exception while a chunk is scored must end the CLI with that exception — not leave the tokeniser thread
+    blocked on its queue (and the process alive) behind it."""
+    import threading
+    from clip_amd import scoring
+    cfg = BertConfig(vocab_size=2000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=512)
+    model_dir = tmp_path / "model"
+    cfg.save_pretrained(str(model_dir))
+    shutil.copyfile(os.path.join(G, "vocab.txt"), model_dir / "vocab.txt")
+    run_dir = tmp_path / "run"
+    run_dir.mkdir()
+    torch.save(procedural_state_dict(cfg, 31), run_dir / "w.pth")
+    calls = []
+    real = scoring.BulkScorer.score
+
+    def flaky(self, *a, **k):
+        calls.append(1)
+        if len(calls) == 2:
+            raise RuntimeError("injected")
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(scoring.BulkScorer, "score", flaky)
+    before = threading.active_count()
+    with pytest.raises(RuntimeError, match="injected"):
+        apply_bert_unlabeled.main([os.path.join(G, "notes_synth.csv"), str(model_dir), str(run_dir / "w.pth"),
+                                   "--n_context_sentences", "2", "--chunk_rows", "5", "--tokens_per_step", "4096"])
+    import time
+    for _ in range(50):                 # the producer notices within its 0.2 s put timeout
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.1)
+    assert threading.active_count() <= before
