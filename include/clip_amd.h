@@ -73,7 +73,9 @@ int clip_finalize_weights(clip_engine* e);
  *     2e-2 budget holds on weights with trained-like statistics (tests/test_gpu_parity_gates.py), where
  *     bf16 operands cannot (their rounding alone is ~0.5 % of the logit spread).  The price is fp16's
  *     RANGE: a weight beyond +-65504 is refused at load; an activation beyond it becomes inf and the
- *     logits NaN (never silently wrong).  BERT-base activations stay far inside it. */
+ *     logits NaN (never silently wrong).  BERT-base activations stay far inside it.  In this setting the
+ *     LayerNorm output is kept ONCE (fp16, row-major: GEMM operand and residual are the same bits), where
+ *     the bf16 setting keeps a bf16 operand copy and an fp16 residual copy. */
 enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1, CLIP_PRECISION_F16 = 2 };
 int clip_set_precision(clip_engine* e, int32_t precision);
 
