@@ -177,14 +177,20 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, &e->mid_rows, S * I * es);
   for (int b = 0; b < 2; ++b) rc = rc ? rc : dev_alloc(e, (void**)&e->stats_rows[b], S * 8);
   const size_t n_tiles = (Tp / 256) * ((H + 255) / 256);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->xres, Tp * H * 2);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
+  // the separate fp16 residual copies exist in the bf16 setting only (f16: x itself; fp32: not fused)
+  const bool two_copies = !e->f32 && !e->f16;
+  if (two_copies) {
+    rc = rc ? rc : dev_alloc(e, (void**)&e->xres, Tp * H * 2);
+    rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
+  }
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   if (rc) return rc;
-  HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
-  HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
+  if (two_copies) {
+    HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
+    HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
+  }
   HIP_TRY(hipMemset(e->lnflags, 0, n_tiles * 4));
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
