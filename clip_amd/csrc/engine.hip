@@ -859,6 +859,20 @@ int clip_gemm_bf16_lnout(const uint16_t* A, const uint16_t* W, const float* bias
   return CLIP_OK;
 }
 
+int clip_gemm_f16_lnout_inplace(const uint16_t* A, const uint16_t* W, const float* bias, const float* gamma,
+                                const float* beta, float eps, uint16_t* x_inout, float* part, uint32_t* flags,
+                                uint32_t epoch, int32_t* err, int32_t M, int32_t N, int32_t K, int32_t lda,
+                                int32_t ldw, int32_t ldx, void* stream) {
+  GemmArgs g{A, W, bias, x_inout, x_inout, M, N, K, lda, ldw, ldx, ldx, EPI_BIAS_LNOUT, false, 2};
+  g.ln_gamma = gamma; g.ln_beta = beta;
+  g.lnout = LnOutArgs{nullptr, false, part, flags, epoch, eps, err};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  if (!x_inout || !part || !flags || !err || N / 256 > 8 || A == x_inout)
+    return fail(CLIP_ERR_ARG, "clip_gemm_f16_lnout_inplace: null buffer, A aliasing x, or more than 8 column tiles");
+  HIP_TRY(k_f16::launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
 int clip_gemm_bf16_lnout_noalloc(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* res16,
                                  int32_t res_tiled, const float* gamma, const float* beta, float eps,
                                  uint16_t* x_out, uint16_t* xres_out, int32_t* err, int32_t M, int32_t N,

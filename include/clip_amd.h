@@ -184,6 +184,16 @@ int clip_gemm_bf16_lnout(const uint16_t* dev_A, const uint16_t* dev_W, const flo
                          float eps, uint16_t* dev_x_out, uint16_t* dev_xres_out, float* dev_part,
                          uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M, int32_t N,
                          int32_t K, int32_t lda, int32_t ldw, int32_t ldo, int32_t ldres, void* stream);
+/* The f16 setting's form of clip_gemm_bf16_lnout (fp16 operands, CLIP_PRECISION_F16; same reference math,
+ * modeling_bert.py:289-293 / :347-351): operand copy and residual copy would hold the same fp16 bits, so there is
+ * ONE buffer.  x_inout [M, N] (row stride ldx, fp16) holds the residual on entry and LayerNorm(A W^T + bias +
+ * residual) on return; every workgroup reads exactly the elements it rewrites.  A must not alias x_inout.
+ * part / flags / epoch / err as clip_gemm_bf16_lnout. */
+int clip_gemm_f16_lnout_inplace(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                                const float* dev_gamma, const float* dev_beta, float eps, uint16_t* dev_x_inout,
+                                float* dev_part, uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M,
+                                int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldx, void* stream);
+
 /* clip_gemm_bf16_lnout for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, kernel and
  * result bits as clip_gemm_bf16_lnout, minus dev_part / dev_flags / epoch: the exchange buffers live in

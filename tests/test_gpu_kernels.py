@@ -461,6 +461,46 @@ def test_gemm_f16_operand_set(lib, M, N, K, epi, out_f32, tile):
     assert (out.float() - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(255 * 256, 768, 768), (36 * 256, 768, 3072), (256, 768, 768), (3 * 256, 1024, 512)])
+def test_gemm_f16_fused_layernorm_in_place(lib, M, N, K):
+    """The f16 setting's fused-LayerNorm GEMM: ONE fp16 buffer holds the residual on entry and
+    LayerNorm(A W^T + bias + residual) on return (operand copy = residual copy).  Against an fp64 reference, same
+    bits across calls (new epoch, same scratch), and the buffer's other content (a wider row stride) untouched."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
+    A = torch.randn(M, K, generator=g).to(torch.float16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.float16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = (torch.randn(M, N, generator=g) * 1.5 + 0.2).to(torch.float16).cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    nt = (M // 256) * (N // 256)
+    part = torch.empty(nt * 256 * 2, device="cuda")
+    flags = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    v = A.double() @ W.double().T + bias.double() + res.double()
+    ref, _, _ = _ln_ref(v, gamma.double(), beta.double())
+    outs = []
+    for epoch, ldx in ((1, N), (2, N), (3, N + 64)):
+        buf = torch.full((M, ldx), 7.0, dtype=torch.float16, device="cuda")
+        buf[:, :N] = res
+        _lib.check(lib.clip_gemm_f16_lnout_inplace(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta),
+                                                   1e-12, _lib.ptr(buf), _lib.ptr(part), _lib.ptr(flags), epoch,
+                                                   _lib.ptr(err), M, N, K, K, K, ldx, _lib.stream_ptr()))
+        _sync()
+        assert int(err.item()) == 0
+        x = buf[:, :N]
+        assert torch.isfinite(x.float()).all()
+        assert (x.double() - ref).abs().max().item() < 4e-3 + 2 ** -10 * ref.abs().max().item()
+        if ldx > N:
+            assert (buf[:, N:] == 7.0).all()
+        outs.append(x.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if K == N:      # A must not alias the in-place buffer
+        assert lib.clip_gemm_f16_lnout_inplace(_lib.ptr(res), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(gamma),
+                                               _lib.ptr(beta), 1e-12, _lib.ptr(res), _lib.ptr(part), _lib.ptr(flags), 9,
+                                               _lib.ptr(err), M, N, K, K, K, N, _lib.stream_ptr()) != 0
+
+
 def test_attention_f16_operand_set(lib):
     heads, H = 12, 768
     lens = [1, 7, 64, 65, 128, 129, 200, 256, 300, 512]
