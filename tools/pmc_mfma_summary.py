@@ -13,14 +13,21 @@ import sys
 
 CUS = 256
 PAT = re.compile(r"(gemm8_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|layernorm_kernel|embed_ln_kernel)")
+
+
+def key(name):     # as tools/pmc_summary.py: the default SINGLE = false template argument is left out of the key
+    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false>", name)
+    return m.group(1) + ">" if m else name
+
+
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     m = PAT.search(r["Kernel_Name"])
     if not m or int(r["Grid_Size"]) < 65536:
         continue
-    agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    dur[m.group(1)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    agg[key(m.group(1))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur[key(m.group(1))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {}
 for k, v in agg.items():
     med = {c: sorted(x)[len(x) // 2] for c, x in v.items()}

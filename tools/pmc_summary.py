@@ -5,8 +5,15 @@ so fetch is doubled; WRITE_SIZE is exact for 16-B stores.  Usage:
     python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json [rows_per_step seq_len]"""
 import collections, csv, json, re, sys
 
-PAT = re.compile(r"(gemm8_kernel<\d, \w+(?:, \w+)?>|gemm_persist_kernel<\d, \w+>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
+PAT = re.compile(r"(gemm8_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|attention_kernel|attention_focus_kernel|"
                  r"layernorm_kernel|embed_ln_kernel)")
+
+
+def key(name):
+    """gemm8_kernel<EPI, OUT_F32, RES_TILED, SINGLE>: the default SINGLE = false is left out, so the keys of
+    earlier summaries (three arguments) stay valid"""
+    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false>", name)
+    return m.group(1) + ">" if m else name
 
 
 def load(name, f):
@@ -14,7 +21,7 @@ def load(name, f):
     for r in csv.DictReader(open(f)):
         m = PAT.search(r["Kernel_Name"])
         if r["Counter_Name"] == name and m and int(r["Grid_Size"]) >= 65536:
-            agg[m.group(1)].append(float(r["Counter_Value"]) * 1024)      # KB -> bytes
+            agg[key(m.group(1))].append(float(r["Counter_Value"]) * 1024)      # KB -> bytes
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 

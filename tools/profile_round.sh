@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
-B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 cp "$(ls "$OUT"/stats/*/*kernel_stats.csv | head -1)" "$OUT/kernel_stats.csv"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $B > /dev/null 2> "$OUT/pmc_fetch.err"
