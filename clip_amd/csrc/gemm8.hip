@@ -48,6 +48,9 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 #ifndef GEMM8_SPLIT
 #define GEMM8_SPLIT 0   // 1: the second half-tile of each phase's staging is issued in the middle of the phase's MFMA block
 #endif
+#ifndef LNOUT_NT_RES
+#define LNOUT_NT_RES 1   // 0: diagnostic builds with cached residual loads in the fused-LayerNorm epilogue
+#endif
 #ifndef GEMM8_STORE
 #define GEMM8_STORE 0   // diagnostic builds: 0 non-temporal output stores, 1 plain
 #endif
@@ -394,7 +397,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) {
+              // read once: non-temporal, so that 128 KB per tile do not push the W tile and the A panels out of the
+              // XCD's L2 (attn-out 220.6 -> 200.1 us at M = 130 560; FFN-down, whose W slice does not fit anyway, unchanged)
+#if LNOUT_NT_RES
+              const f16x8_t r = __builtin_nontemporal_load(reinterpret_cast<const f16x8_t*>(rt + (mh * 4 + m) * 1024 + nh * 512));
+#else
               const f16x8_t r = *reinterpret_cast<const f16x8_t*>(rt + (mh * 4 + m) * 1024 + nh * 512);
+#endif
 #pragma unroll
               for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -414,19 +423,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
 #pragma unroll
         for (int mb = 0; mb < 8; mb += 2) {   // two 16-row blocks (4 loads) in flight
           __builtin_amdgcn_sched_barrier(0);
-          uint4 rv[2][2];
+          u32x4_t rv[2][2];
 #pragma unroll
           for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
               const int mh = (mb + k) >> 2, m = (mb + k) & 3;
-              rv[k][p] = *reinterpret_cast<const uint4*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo);
+#if LNOUT_NT_RES
+              rv[k][p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo));
+#else
+              rv[k][p] = *reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo);
+#endif
             }
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int mh = (mb + k) >> 2, m = (mb + k) & 3;
-            *reinterpret_cast<uint4*>(scw) = rv[k][0];
-            *reinterpret_cast<uint4*>(scw + 1024) = rv[k][1];
+            *reinterpret_cast<u32x4_t*>(scw) = rv[k][0];
+            *reinterpret_cast<u32x4_t*>(scw + 1024) = rv[k][1];
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
