@@ -39,7 +39,7 @@ __device__ uint32_t g_attn_stamps[4096 * 16];
 #define A_STAMP_T(k)
 #endif
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
                                                         int q_tiles, int n_heads, int n_pairs) {
@@ -220,21 +220,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   }
 
   A_STAMP(8)
+  // ---- output: each wave's 32 x 64 block through its 4-KiB quarter of the (now idle) K/V tiles, out as whole
+  // 128-byte row segments (16 B per lane, 8 rows per instruction, non-temporal: ctx is read by the next kernel,
+  // not by this one) instead of 16 stores of 8 bytes per lane
+  __syncthreads();  // every wave is done reading the last key tile
   if (!wave_live) return;
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
-  const int q = q0 + l31;
-  if (q < len) {
-    bf16_t* dst = ctx + (size_t)(beg + q) * hidden + head * HD;
+  char* ot = (w < 2 ? k_lds : v_lds) + (w & 1) * 4096;   // [32 q rows][128 B], 8-byte slots XOR-swizzled in pairs
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * db + 8 * g + 4 * h;
-        *reinterpret_cast<uint2*>(dst + d) =
-            make_uint2(pack_op2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                       pack_op2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int sl = (8 * db + 2 * g + h) ^ ((l31 & 7) << 1);
+      *reinterpret_cast<uint2*>(ot + l31 * 128 + sl * 8) =
+          make_uint2(pack_op2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                     pack_op2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+    }
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = p * 8 + (lane >> 3), c16 = lane & 7;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ot + row * 128 + ((c16 ^ (row & 7)) * 16));
+    if (q0 + row < len)
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(ctx + (size_t)(beg + q0 + row) * hidden + head * HD + c16 * 8));
   }
   A_STAMP(9)
 }
