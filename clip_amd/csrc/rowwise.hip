@@ -55,10 +55,16 @@ __device__ __forceinline__ void ln_finish(float (&x)[NIT][VEC], const float* gam
 #pragma unroll
     for (int v = 0; v < VEC; ++v) y[v] = ln_apply(x[it][v], mean, rstd, g[v], b[v]);
     if (res16) {  // fp16 copy of the same fp32 values: the residual operand of EPI_BIAS_LNOUT / RES16
+      if (VEC == 4) {  // one 8-byte store per lane, not four 2-byte ones
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4_t;
+        const h4_t hv = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+        *reinterpret_cast<h4_t*>(res16 + e) = hv;
+      } else {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const _Float16 hv = (_Float16)y[v];
-        res16[e + v] = *reinterpret_cast<const uint16_t*>(&hv);
+        for (int v = 0; v < VEC; ++v) {
+          const _Float16 hv = (_Float16)y[v];
+          res16[e + v] = *reinterpret_cast<const uint16_t*>(&hv);
+        }
       }
     }
     if (OUT_F32) {
