@@ -39,6 +39,12 @@ __device__ uint32_t g_attn_stamps[4096 * 16];
 #define A_STAMP_T(k)
 #endif
 
+// KV_ONCE: every sequence of the launch has one q tile (max_seqlen <= 128), so each K/V row is read exactly once:
+// loaded non-temporally (the kernel alone, 130 560 tokens at L = 128, same qkv every launch: 162 -> 130 us; inside
+// the engine, where qkv has just been written: 1.80 -> 1.77 ms per step).  With several q tiles per sequence the
+// later ones find the rows in L2 and the hint costs 12 %, so those launches keep the cached form.  (One kernel
+// with a per-workgroup choice compiles to the cached form for both: the optimiser merges the two loads.)
+template <bool KV_ONCE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
@@ -95,8 +101,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int i = 0; i < 2; ++i) {
       const int r = kv0 + st_row + 32 * i;
       if (r < len) {
-        kreg[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)r * ld + st_chunk * 8);
-        vreg[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)r * ld + st_chunk * 8);
+        if (KV_ONCE) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int u4_t;
+          const u4_t kk = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(kbase + (size_t)r * ld + st_chunk * 8));
+          const u4_t vv4 = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(vbase + (size_t)r * ld + st_chunk * 8));
+          kreg[i] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+          vreg[i] = make_uint4(vv4[0], vv4[1], vv4[2], vv4[3]);
+        } else {
+          kreg[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)r * ld + st_chunk * 8);
+          vreg[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)r * ld + st_chunk * 8);
+        }
       } else {  // keys past the end: zero (masked below; V must not carry NaN into 0 * V)
         kreg[i] = make_uint4(0, 0, 0, 0);
         vreg[i] = make_uint4(0, 0, 0, 0);
@@ -446,12 +460,16 @@ hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, 
 #ifdef ATTN_PAIR
   if (q_tiles == 2) {
     const int n_pairs = n_seqs * n_heads;
-    hipLaunchKernelGGL(attention_kernel, dim3((n_pairs + 7) / 8 * 16), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
+    hipLaunchKernelGGL(attention_kernel<false>, dim3((n_pairs + 7) / 8 * 16), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
                        q_tiles, n_heads, n_pairs);
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL(attention_kernel, dim3(q_tiles * n_seqs, n_heads), dim3(256), 0, st, qkv,
-                     cu_seqlens, ctx, hidden, q_tiles, n_heads, 0);
+  if (q_tiles == 1)
+    hipLaunchKernelGGL(attention_kernel<true>, dim3(n_seqs, n_heads), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
+                       q_tiles, n_heads, 0);
+  else
+    hipLaunchKernelGGL(attention_kernel<false>, dim3(q_tiles * n_seqs, n_heads), dim3(256), 0, st, qkv,
+                       cu_seqlens, ctx, hidden, q_tiles, n_heads, 0);
   return hipGetLastError();
 }
