@@ -57,11 +57,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   int seq, head, qt;
   if (n_pairs > 0) {
-    // q_tiles == 2, 1-D grid: the two q tiles of a (sequence, head) get workgroup ids 8 apart — the same XCD
-    // (ids go round-robin over the 8 XCDs), dispatched together, so the second one's K/V reads can hit that L2
-    const int id = blockIdx.x, pair = (id >> 4) * 8 + (id & 7);
+    // q_tiles >= 2, 1-D grid: the q tiles of a (sequence, head) get workgroup ids 8 apart — the same XCD (ids go
+    // round-robin over the 8 XCDs), dispatched together, so the later ones' K/V reads can hit that L2
+    const int id = blockIdx.x, blk = id / (8 * q_tiles), r = id - blk * 8 * q_tiles;
+    const int pair = blk * 8 + (r & 7);
     if (pair >= n_pairs) return;
-    qt = (id >> 3) & 1;
+    qt = r >> 3;
     seq = pair / n_heads;
     head = pair - seq * n_heads;
   } else {
@@ -461,9 +462,9 @@ hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, 
   if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;
   const int q_tiles = (max_seqlen + 127) / 128;
 #if ATTN_PAIR   // bench.py in alternating processes: attention 1.956 -> 1.903 ms per step (3 of 3 pairs of runs)
-  if (q_tiles == 2) {
+  if (q_tiles >= 2) {
     const int n_pairs = n_seqs * n_heads;
-    hipLaunchKernelGGL(attention_kernel<false>, dim3((n_pairs + 7) / 8 * 16), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
+    hipLaunchKernelGGL(attention_kernel<false>, dim3((n_pairs + 7) / 8 * 8 * q_tiles), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
                        q_tiles, n_heads, n_pairs);
     return hipGetLastError();
   }
