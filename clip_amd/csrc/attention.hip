@@ -296,29 +296,39 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   q_s[lane] = op_to_f32(q_rows ? q_rows[(size_t)seq * hidden + head * HD + lane]
                                  : qkv[(size_t)focus[seq] * ld + head * HD + lane]);
   __syncthreads();
+  // 8 lanes per key row: lane (g, c) takes dims 8c .. 8c+7 of key 8 it + g, so every load instruction covers 8
+  // whole 128-byte rows (one lane per key meant 64 rows x 16 B per instruction); the 8 partial dot products meet
+  // by three xor-shuffles
+  const int g = lane >> 3, c = lane & 7;
+  float qv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qv[e] = q_s[c * 8 + e];
+  const int n_it = (len + 7) >> 3;
+  for (int it = 0; it < n_it; ++it) {
+    const int key = it * 8 + g;
+    float d = 0.f;
+    if (key < len) {
+      const uint4 kv = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8);
+      const uint32_t wds[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d = fmaf(op2_lo(wds[e]), qv[2 * e], d);
+        d = fmaf(op2_hi(wds[e]), qv[2 * e + 1], d);
+      }
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0 && key < len) p_s[key] = d * LOG2E;
+  }
+  __syncthreads();
   float sc[8];
   float mx = -INFINITY;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int key = lane + 64 * i;
-    float d = -INFINITY;
-    if (key < len) {
-      d = 0.f;
-      const uint4* kr = reinterpret_cast<const uint4*>(kbase + (size_t)key * ld);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const uint4 kv = kr[c];
-        const uint32_t wds[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          d = fmaf(op2_lo(wds[e]), q_s[c * 8 + 2 * e], d);
-          d = fmaf(op2_hi(wds[e]), q_s[c * 8 + 2 * e + 1], d);
-        }
-      }
-      d *= LOG2E;
-    }
-    sc[i] = d;
-    mx = fmaxf(mx, d);
+    sc[i] = key < len ? p_s[key] : -INFINITY;
+    mx = fmaxf(mx, sc[i]);
   }
   mx = wave_max(mx);
   float sum = 0.f;
@@ -327,13 +337,37 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
     const int key = lane + 64 * i;
     const float p = key < len ? exp2f(sc[i] - mx) : 0.f;
     sum += p;
-    p_s[key] = p;
+    if (key < len) p_s[key] = p;
   }
   sum = wave_sum(sum);
   __syncthreads();
-  float o = 0.f;
-  for (int key = 0; key < len; ++key) o = fmaf(p_s[key], op_to_f32(vbase[(size_t)key * ld + lane]), o);
-  ctx_rows[(size_t)seq * hidden + head * HD + lane] = f32_to_op(o / sum);
+  // o[dims 8c .. 8c+7] over this lane group's keys, then across the 8 groups (xor 8, 16, 32)
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < n_it; ++it) {
+    const int key = it * 8 + g;
+    if (key < len) {
+      const float p = p_s[key];
+      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (size_t)key * ld + c * 8);
+      const uint32_t wds[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = fmaf(p, op2_lo(wds[e]), o[2 * e]);
+        o[2 * e + 1] = fmaf(p, op2_hi(wds[e]), o[2 * e + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o[e] += __shfl_xor(o[e], 8, 64);
+    o[e] += __shfl_xor(o[e], 16, 64);
+    o[e] += __shfl_xor(o[e], 32, 64);
+  }
+  if (g == 0) {
+    const float inv = 1.0f / sum;
+    *reinterpret_cast<uint4*>(ctx_rows + (size_t)seq * hidden + head * HD + c * 8) =
+        make_uint4(pack_op2(o[0] * inv, o[1] * inv), pack_op2(o[2] * inv, o[3] * inv),
+                   pack_op2(o[4] * inv, o[5] * inv), pack_op2(o[6] * inv, o[7] * inv));
+  }
 }
 
 // fp32 check mode: the same softmax(q k^T) v on fp32 q/k/v with fp32 arithmetic throughout (no
