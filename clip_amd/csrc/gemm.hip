@@ -315,6 +315,7 @@ const char* gemm_check(const GemmArgs& g) {
   if (g.epi == EPI_BIAS_RES16 && (!g.res || g.ldres % 4 || !g.out_f32 || g.f32_in)) return "gemm: fp16-residual epilogue needs fp16 rows and an fp32 output";
   if (g.epi == EPI_BIAS_LNOUT && (g.tile != 2 || g.out_f32 || g.f32_in || !gemm_persist_ok(g) || !g.ln_gamma || !g.ln_beta))
     return "gemm: the fused-LayerNorm epilogue runs on the ping-pong kernel only (tile 2, bf16 out, M and N multiples of 256)";
+  if (g.epi == EPI_BIAS_LNOUT && (g.ldres % 8 || g.ldo % 8)) return "gemm: the fused-LayerNorm epilogue needs 16-byte rows (ldo, ldres multiples of 8)";
   if (g.res_index && g.epi != EPI_BIAS_LNRES && g.epi != EPI_BIAS_RES16) return "gemm: res_index only with the residual-row epilogues";
   if (!g.A || !g.W || !g.bias || !g.out) return "gemm: null operand";
   if (g.tile != 0 && g.tile != 128 && g.tile != 256 && g.tile != 2) return "gemm: tile must be 0 (auto), 2 (ping-pong persistent), 128 or 256";

@@ -411,14 +411,16 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
                   acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[i * 4 + e];
             }
         }
-      } else if (SINGLE) {
-        // The residual IS the output buffer's current content (read through `out`, not through the second
-        // restrict-qualified pointer); these loads come before the barriers of the exchange, the stores after.
-        // Whole 128-byte row segments (16 B per lane, 8 rows per instruction) through this wave's transpose
-        // scratch, read back in accumulator layout — the output path backwards; 4 blocks (8 loads) in flight.
-        const uint16_t* xr = reinterpret_cast<const uint16_t*>(out);
+      } else {
+        // Row-major fp16 residual: the first layer's (the embedding LayerNorm's copy), or — SINGLE — the output
+        // buffer's current content (read through `out`, not through the second restrict-qualified pointer; these
+        // loads come before the barriers of the exchange, the stores after).  Whole 128-byte row segments (16 B
+        // per lane, 8 rows per instruction) through this wave's transpose scratch, read back in accumulator
+        // layout — the output path backwards; two blocks (4 loads) in flight.
+        const uint16_t* xr = SINGLE ? reinterpret_cast<const uint16_t*>(out) : reinterpret_cast<const uint16_t*>(resv);
+        const int ldr = SINGLE ? ldo : ldres;
         const int lrow = lane >> 3, c16 = lane & 7;
-        const uint16_t* xr0 = xr + ((size_t)tm * BM + wr * 64 + lrow) * ldo + n_base + c16 * 8;
+        const uint16_t* xr0 = xr + ((size_t)tm * BM + wr * 64 + lrow) * ldr + n_base + c16 * 8;
         char* scw = scr + lrow * 128 + ((c16 ^ (lrow & 7)) * 16);   // (row + 8) & 7 == row & 7: + 1024 for p = 1
 #pragma unroll
         for (int mb = 0; mb < 8; mb += 2) {   // two 16-row blocks (4 loads) in flight
@@ -430,9 +432,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
             for (int p = 0; p < 2; ++p) {
               const int mh = (mb + k) >> 2, m = (mb + k) & 3;
 #if LNOUT_NT_RES
-              rv[k][p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo));
+              rv[k][p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldr));
 #else
-              rv[k][p] = *reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldo);
+              rv[k][p] = *reinterpret_cast<const u32x4_t*>(xr0 + (size_t)(mh * 128 + m * 16 + p * 8) * ldr);
 #endif
             }
 #pragma unroll
@@ -451,22 +453,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               }
           }
         }
-      } else {
-        const f16x4_t* res16 = reinterpret_cast<const f16x4_t*>(resv);
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const size_t rg = ((size_t)tm * BM + mh * 128 + wr * 64 + m * 16 + fr) * ldres;
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-              for (int i = 0; i < 2; ++i) {
-                const f16x4_t r = res16[(rg + n_base + nh * 32 + i * 16 + fq * 4) >> 2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mh][nh][m][i][e] = (acc[mh][nh][m][i][e] + bv[nh][i][e]) + (float)r[e];
-              }
-          }
       }
       LN_STAMP(2)
       // (2) per-row (sum, sum of squares) over this wave's 64 columns -> LDS, one slot per column wave
