@@ -57,19 +57,34 @@ class RunningTopK:
 
 def run_rank(scorer, config, n_rows, chunk_rows_n, k, rank, world, vocab_size, on_chunk=None):
     """Score this rank's chunks; returns (RunningTopK, rows, tokens, kept)."""
+    from concurrent.futures import ThreadPoolExecutor
     n_chunks = (n_rows + chunk_rows_n - 1) // chunk_rows_n
     top = RunningTopK(k)
     rows_done = tokens = kept = 0
-    for c in range(rank, n_chunks, world):
-        n = min(chunk_rows_n, n_rows - c * chunk_rows_n)
-        rows, doc_ids, sent_ixs = chunk_rows(config, c, n, vocab_size)
+    mine = list(range(rank, n_chunks, world))
+    size = lambda c: min(chunk_rows_n, n_rows - c * chunk_rows_n)
+    pool = ThreadPoolExecutor(max_workers=1)      # the next chunk's rows are made while this one is scored
+    post = ThreadPoolExecutor(max_workers=1)      # ... and the previous chunk's records are folded into the top-k
+    nxt = pool.submit(chunk_rows, config, mine[0], size(mine[0]), vocab_size) if mine else None
+    fold = None
+    for i, c in enumerate(mine):
+        n = size(c)
+        rows, doc_ids, sent_ixs = nxt.result()
+        if i + 1 < len(mine):
+            nxt = pool.submit(chunk_rows, config, mine[i + 1], size(mine[i + 1]), vocab_size)
         res = scorer.score(rows, doc_ids, sent_ixs)
-        top.update(res.doc_ids, res.sent_ixs, res.max_score, keep=res.keep)
+        if fold is not None:
+            fold.result()
+        fold = post.submit(top.update, res.doc_ids, res.sent_ixs, res.max_score, res.keep)   # under the next chunk
         rows_done += n
         tokens += int(rows.lens.sum())
         kept += int(res.keep.sum())
         if on_chunk is not None:
             on_chunk(c, n, res)
+    if fold is not None:
+        fold.result()
+    pool.shutdown(wait=False)
+    post.shutdown(wait=False)
     return top, rows_done, tokens, kept
 
 
