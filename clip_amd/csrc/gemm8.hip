@@ -267,15 +267,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         if (v1) {
           stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
           if (GEMM8_SPLIT == 0) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
-#ifdef GEMM8_EXTRA_DMA  // experiment: 1.5x the DMA pieces per MFMA (the same half-tile staged twice: identical bytes)
-          stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
-          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#else
           // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
           // (t).A1, read next phase, is older
           if (GEMM8_SPLIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#endif
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -318,17 +313,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         if (v2) {
           stage_half(a2, a_off, lda, B * 4 + 0);
           if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ldw, B * 4 + 1);
-#ifdef GEMM8_EXTRA_DMA
-          stage_half(w2, w_off, ldw, B * 4 + 1);
-#endif
         }
         advance();
         if (staged2) {
-#ifdef GEMM8_EXTRA_DMA
-          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#else
           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -576,11 +564,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
                   make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
             }
-#ifndef LNOUT_NO_XRES_STORE   // timing experiment: one output copy only
             if (!SINGLE)
               out_store(*reinterpret_cast<const u32x4_t*>(&hv),
                         reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
-#endif
           }
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
