@@ -16,6 +16,7 @@ tests/test_gpu_job.py checks.
 import argparse
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -113,6 +114,7 @@ def main(argv=None):
                         help="operand type of the GEMM / attention kernels (clip_set_precision)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start, one per MI355X (ignored under torchrun)")
     ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
+    ap.add_argument("--progress", action="store_true", help="one line per scored chunk on stderr")
     args = ap.parse_args(argv)
 
     # --gpus N: this process starts the N ranks itself (clip_amd/launch.py); under torchrun they exist already
@@ -147,8 +149,11 @@ def main(argv=None):
 
     barrier()
     t0 = time.perf_counter()
+    def progress(c, n, res):
+        print(f"[rank {rank}] chunk {c}: {n} rows, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+
     top, rows_done, tokens, kept = run_rank(scorer, args.config, args.rows, args.chunk_rows, args.topk, rank, world,
-                                            cfg.vocab_size)
+                                            cfg.vocab_size, on_chunk=progress if args.progress else None)
     torch.cuda.synchronize()
     t_score = time.perf_counter() - t0
     glob = topk.global_topk(top.records, args.topk)
