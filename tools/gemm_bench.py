@@ -47,6 +47,10 @@ if os.environ.get("SHAPES") == "res":   # what does the residual read cost the f
 g = torch.Generator(device="cpu").manual_seed(0)
 for sname, N, K, epi, f32 in shapes:
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    # ROTATE=n: n copies of A used in turn, so that the operand does not stay in the 256-MiB Infinity Cache
+    # between launches (in the engine every GEMM reads an operand the kernel before it has just written)
+    A_all = [A] + [A.clone() for _ in range(int(os.environ.get("ROTATE", "1")) - 1)]
+    calls = [0]
     W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).cuda()
     bias = torch.randn(N, generator=g).cuda()
     res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
@@ -66,6 +70,8 @@ for sname, N, K, epi, f32 in shapes:
         epoch = [0]
 
     def run(v):
+        A = A_all[calls[0] % len(A_all)]
+        calls[0] += 1
         if epi == 5:
             epoch[0] += 1
             rc = libs[v[0]].clip_gemm_bf16_lnout(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(xres), int(os.environ.get("RES_TILED", "1")), _lib.ptr(gamma),
