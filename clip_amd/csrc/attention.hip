@@ -51,7 +51,7 @@ template <bool KV_ONCE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
-                                                        int q_tiles, int n_heads, int n_pairs) {
+                                                        int q_tiles, int n_heads, int n_pairs, int ctx_tiled) {
   __shared__ __attribute__((aligned(16))) char k_lds[KT * 128];
   __shared__ __attribute__((aligned(16))) char v_lds[KT * 128];
 
@@ -260,8 +260,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int p = 0; p < 4; ++p) {
     const int row = p * 8 + (lane >> 3), c16 = lane & 7;
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ot + row * 128 + ((c16 ^ (row & 7)) * 16));
-    if (q0 + row < len)
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(ctx + (size_t)(beg + q0 + row) * hidden + head * HD + c16 * 8));
+    if (q0 + row < len) {
+      // ctx_tiled: the out-projection's A operand as contiguous 128 x 64 blocks (a head is one block column)
+      const size_t r = (size_t)(beg + q0 + row);
+      const size_t at = ctx_tiled ? operand_tiled_offset(r, head * HD + c16 * 8, hidden) : r * hidden + head * HD + c16 * 8;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(ctx + at));
+    }
   }
   A_STAMP(9)
 }
@@ -491,7 +495,8 @@ hipError_t KSET::launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seq
 }
 
 hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx, int n_seqs,
-                            int max_seqlen, int n_heads, int hidden, hipStream_t st) {
+                            int max_seqlen, int n_heads, int hidden, hipStream_t st, bool ctx_tiled) {
+  const int ct = ctx_tiled ? 1 : 0;
   if (n_seqs <= 0) return hipSuccess;
   if (hidden != n_heads * HD || max_seqlen <= 0) return hipErrorInvalidValue;
   const int q_tiles = (max_seqlen + 127) / 128;
@@ -499,15 +504,15 @@ hipError_t KSET::launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, 
   if (q_tiles >= 2) {
     const int n_pairs = n_seqs * n_heads;
     hipLaunchKernelGGL(attention_kernel<false>, dim3((n_pairs + 7) / 8 * 8 * q_tiles), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
-                       q_tiles, n_heads, n_pairs);
+                       q_tiles, n_heads, n_pairs, ct);
     return hipGetLastError();
   }
 #endif
   if (q_tiles == 1)
     hipLaunchKernelGGL(attention_kernel<true>, dim3(n_seqs, n_heads), dim3(256), 0, st, qkv, cu_seqlens, ctx, hidden,
-                       q_tiles, n_heads, 0);
+                       q_tiles, n_heads, 0, ct);
   else
     hipLaunchKernelGGL(attention_kernel<false>, dim3(q_tiles * n_seqs, n_heads), dim3(256), 0, st, qkv,
-                       cu_seqlens, ctx, hidden, q_tiles, n_heads, 0);
+                       cu_seqlens, ctx, hidden, q_tiles, n_heads, 0, ct);
   return hipGetLastError();
 }

@@ -77,6 +77,12 @@ __device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float
   return fmaf((x - mean) * rstd, g, b);
 }
 
+// Element (r, c) of a 16-bit [M, C] GEMM operand kept as contiguous 128 x 64 blocks (GemmArgs::a_tiled / out_tiled;
+// M a multiple of 128, C of 64): a 128-byte row segment stays whole, a block is 16 KiB.
+__host__ __device__ __forceinline__ size_t operand_tiled_offset(size_t r, int c, int C) {
+  return ((((r >> 7) * (size_t)(C >> 6)) + (size_t)(c >> 6)) << 13) + ((r & 127) << 6) + (size_t)(c & 63);
+}
+
 // The fp16 residual copy of the fused-LayerNorm flow is kept TILED for the accumulator layout of the
 // 256x256 GEMM tile, so that the workgroup that wrote a tile reads it back (as the next residual)
 // with whole 1-KiB wave accesses and no transpose.  Element (row, col) of an [M, N] tensor, N a

@@ -301,10 +301,10 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // read as the residual and rewritten in place by the fused GEMMs (no xres / xres_rm traffic at all)
   constexpr bool single = std::is_same<KS, k_f16>::value;
   auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
-                     const float* beta) {
+                     const float* beta, bool a_tiled) {
     GemmArgs a{A, W, bias, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres), e->x, M, H, K,
                K, K, H, H, EPI_BIAS_LNOUT, false, 2};
-    a.ln_gamma = gamma; a.ln_beta = beta;
+    a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled;
     a.lnout = LnOutArgs{single ? nullptr : e->xres, !single && !first_res, e->lnpart, e->lnflags, ++e->epoch,
                         c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u};
     first_res = false;
@@ -329,6 +329,11 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   const int Tg = f32 ? T : (T + 255) / 256 * 256;
   // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
   // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
+  // Fused flow: the two operands with ONE writer and ONE reader — attention's ctx (-> attn-out) and the FFN
+  // intermediate (-> FFN-down) — are kept as contiguous 128 x 64 blocks (GemmArgs::a_tiled); the intermediate only
+  // when FFN-up itself runs on the ping-pong kernel (launch_gemm's rule), which alone writes that layout.  The layout
+  // moves bytes, not arithmetic: a row's result does not depend on it.
+  const bool mid_tiled = fused && (long)(Tg / 256) * (I / 256) >= 256 && I % 256 == 0 && H % 128 == 0;
   const bool trim = e->trim_last && c.max_position <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
@@ -358,11 +363,11 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
                                      n_seqs, max_seqlen, c.num_heads, H, st));
       else
         HIP_TRY(KS::launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
-                                 n_seqs, max_seqlen, c.num_heads, H, st));
+                                 n_seqs, max_seqlen, c.num_heads, H, st, fused));
     }
     if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b));
+      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b, true));
     } else {
       {
         ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
@@ -379,11 +384,12 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
       g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
+      if (mid_tiled) { g.tile = 2; g.out_tiled = true; }
       HIP_TRY(KS::launch_gemm(g, st));
     }
     if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b));
+      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b, mid_tiled));
     } else {
       {
         ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);

@@ -24,6 +24,8 @@
 //    counted (vmcnt(8) / vmcnt(4)): two half-tiles, or four, stay in flight across barriers, and
 //    what a phase reads was retired one barrier earlier.  The stream of half-tiles runs on across
 //    output tiles, so only a workgroup's first tile pays the global->LDS latency.
+//  * A (and the 16-bit output) may be stored as contiguous 128 x 64 blocks (LAYOUT; GemmArgs::a_tiled / out_tiled):
+//    a half-tile is then one 16-KiB block and every LDS-DMA piece 1 KiB contiguous.
 //  * Epilogue (bias / polynomial erf-GELU / residual / tanh, per-wave LDS
 //    transpose, whole 128-byte row segments, non-temporal stores left in flight), through a 2-KiB
 //    scratch per wave beside the ring; the bias slice travels by LDS-DMA one tile ahead.
@@ -97,7 +99,8 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // next GEMM's operand AND as the next residual (in the f16 setting the two copies of the bf16 setting hold the
 // same bits); the residual is then read from the row-major buffer this tile rewrites in place (every wave reads
 // exactly the 64 x 64 blocks it writes).
-template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false>
+// LAYOUT bit 0: A, bit 1: the 16-bit output, stored as contiguous 128 x 64 blocks (GemmArgs::a_tiled / out_tiled)
+template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false, int LAYOUT = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int K, int lda, int ldw, int ldo,
@@ -154,7 +157,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   // the source chunk carries the swizzle (the image the DMA writes is lane-linear)
   const int prow = w * 8 + (lane >> 3);
   const int pchunk = swz128(prow, lane & 7) * 8;
-  const int a_off = prow * lda + pchunk, w_off = prow * ldw + pchunk;
+  // A as contiguous 128 x 64 blocks (operand_tiled_offset): a half-tile of a K tile is ONE block
+  constexpr bool a_tiled = (LAYOUT & 1) != 0, out_tiled = (LAYOUT & 2) != 0;
+  const int ld_a = a_tiled ? 64 : lda, a_kstep = a_tiled ? 8192 : BK;
+  const size_t a_half = a_tiled ? (size_t)(K >> 6) * 8192 : (size_t)128 * lda;   // rows 128.. of the tile
+  const size_t a_panel = a_tiled ? (size_t)BM * K : (size_t)BM * lda;
+  const int a_off = prow * ld_a + pchunk, w_off = prow * ldw + pchunk;
   auto stage_half = [&](const bf16_t* src, int off, int ld, int slot_idx) {
     char* dst = smem + slot_idx * HT + w * 1024;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src + off), LDS_PTR(dst), 16, 0, 0);
@@ -187,27 +195,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       ++s_it;
       v2 = tile_at(s_it, s_tm, s_tn);
       if (!v2) return;
-      a2 = A + (size_t)s_tm * BM * lda;
+      a2 = A + (size_t)s_tm * a_panel;
       w2 = W + (size_t)s_tn * BN * ldw;
     } else {
-      a2 += BK;
+      a2 += a_kstep;
       w2 += BK;
     }
   };
 
   // ---- prologue: K tile 0 whole, the bias slice, three half-tiles of K tile 1
   {
-    const bf16_t* a0 = A + (size_t)tm * BM * lda;
+    const bf16_t* a0 = A + (size_t)tm * a_panel;
     const bf16_t* w0 = W + (size_t)tn * BN * ldw;
-    stage_half(a0, a_off, lda, 0);
+    stage_half(a0, a_off, ld_a, 0);
     stage_half(w0, w_off, ldw, 1);
     stage_half(w0 + (size_t)128 * ldw, w_off, ldw, 2);
-    stage_half(a0 + (size_t)128 * lda, a_off, lda, 3);
+    stage_half(a0 + a_half, a_off, ld_a, 3);
     stage_bias(tn, 0);
     a2 = a0; w2 = w0; v2 = true;
     advance();  // c2 = K tile 1
     advance();  // c1 = K tile 1, c2 = K tile 2 (or the next tile's first)
-    stage_half(a1, a_off, lda, 4);
+    stage_half(a1, a_off, ld_a, 4);
     stage_half(w1, w_off, ldw, 5);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         }
         if (v1) {
           stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
-          if (GEMM8_SPLIT == 0) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+          if (GEMM8_SPLIT == 0) stage_half(a1 + a_half, a_off, ld_a, (B ^ 1) * 4 + 3);
           // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
           // (t).A1, read next phase, is older
           if (GEMM8_SPLIT == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
             }
           if (GEMM8_SPLIT == 1 && ks == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (v1) stage_half(a1 + (size_t)128 * lda, a_off, lda, (B ^ 1) * 4 + 3);
+            if (v1) stage_half(a1 + a_half, a_off, ld_a, (B ^ 1) * 4 + 3);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         const bool staged2 = v2;
         const bf16_t* w2_mid = w2;  // (GEMM8_SPLIT: the W half staged mid-block, after advance() moved the cursor)
         if (v2) {
-          stage_half(a2, a_off, lda, B * 4 + 0);
+          stage_half(a2, a_off, ld_a, B * 4 + 0);
           if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ldw, B * 4 + 1);
         }
         advance();
@@ -444,7 +452,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       }
       LN_STAMP(2)
       // (2) per-row (sum, sum of squares) over this wave's 64 columns -> LDS, one slot per column wave
-      float2* part_lds = reinterpret_cast<float2*>(smem + RING);                       // [4][256], in the scratch
+      // (each wave's 128 row partials go into ITS OWN scratch: a wave that is ahead must not write where another
+      // wave is still transposing its residual rows)
+      float2* part_own = reinterpret_cast<float2*>(scr);                               // [2 mh][4 m][16 rows]
       float2* tot_lds = reinterpret_cast<float2*>(smem + RING + 8 * SCR + 2 * 3072);   // [256] this tile's sums
       float2* stat_lds = tot_lds + 256;                                                // [256] (mean, rstd)
 #pragma unroll
@@ -467,7 +477,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
           sm = xor16_sum(sm); sq = xor16_sum(sq);
           sm = xor32_sum(sm); sq = xor32_sum(sq);
-          if (fq == 0) part_lds[wc * 256 + mh * 128 + wr * 64 + m * 16 + fr] = make_float2(sm, sq);
+          if (fq == 0) part_own[(mh * 4 + m) * 16 + fr] = make_float2(sm, sq);
         }
       __syncthreads();
       LN_STAMP(3)
@@ -485,7 +495,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       //     the flag.  Epochs make a stale flag of an earlier launch unequal to the awaited value.
       const int tile_id = tm * tiles_n + tn;
       if (tid < 256) {
-        const float2 p0 = part_lds[tid], p1 = part_lds[256 + tid], p2 = part_lds[512 + tid], p3 = part_lds[768 + tid];
+        // row tid = (mh, wr, m, fr): its four column waves are wr * 4 + 0..3
+        const float2* pr = reinterpret_cast<const float2*>(smem + RING + ((tid >> 6) & 1) * 4 * SCR) +
+                           ((tid >> 7) * 4 + ((tid >> 4) & 3)) * 16 + (tid & 15);
+        const float2 p0 = pr[0], p1 = pr[SCR / 8], p2 = pr[2 * SCR / 8], p3 = pr[3 * SCR / 8];
         const float2 P = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
         tot_lds[tid] = P;
         unsigned long long bits;
@@ -620,7 +633,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               v = make_uint4(o[0], o[1], o[2], o[3]);
             }
             out_store(*reinterpret_cast<u32x4_t*>(&v),
-                                        reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(out) + mg * ldo + n));
+                      reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(out) +
+                                                 (out_tiled ? operand_tiled_offset(mg, n, ldo) : mg * ldo + n)));
           }
         }
     } else {
@@ -674,9 +688,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false>
+template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false, int LAYOUT = 0>
 hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
-  auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED, SINGLE>;
+  auto kfn = gemm8_kernel<EPI, OUT_F32, RES_TILED, SINGLE, LAYOUT>;
   static DeviceOnce once;  // per instantiation and device: function attribute + workgroup count
   int n_cu = 0;
   hipError_t e0 = once.get([&](int dev, int* val) {
@@ -719,10 +733,14 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
 
 hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
   if (!gemm_persist_ok(g) || g.res_index) return hipErrorInvalidValue;
+  // block layouts: the engine's two single-reader operands only (attention ctx / FFN intermediate -> LayerNorm GEMMs)
+  if (g.a_tiled && (g.lda != g.K || g.epi != EPI_BIAS_LNOUT)) return hipErrorInvalidValue;
+  if (g.out_tiled && (g.ldo != g.N || g.out_f32 || g.a_tiled || g.epi != EPI_BIAS_GELU)) return hipErrorInvalidValue;
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
     case EPI_BIAS * 2 + 0: return launch_8<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_8<EPI_BIAS, true>(g, st);
-    case EPI_BIAS_GELU * 2 + 0: return launch_8<EPI_BIAS_GELU, false>(g, st);
+    case EPI_BIAS_GELU * 2 + 0:
+      return g.out_tiled ? launch_8<EPI_BIAS_GELU, false, false, false, 2>(g, st) : launch_8<EPI_BIAS_GELU, false>(g, st);
     case EPI_BIAS_RES * 2 + 1: return launch_8<EPI_BIAS_RES, true>(g, st);
     case EPI_BIAS_RES * 2 + 0: return launch_8<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
@@ -733,11 +751,15 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
 #if CLIP_OPERAND_F16
         // one copy: operand = residual (fp16), read row-major from the buffer the tile rewrites
         if (g.lnout.res_tiled || g.res != g.out || g.ldres != g.ldo) return hipErrorInvalidValue;
-        return launch_8<EPI_BIAS_LNOUT, false, false, true>(g, st);
+        return g.a_tiled ? launch_8<EPI_BIAS_LNOUT, false, false, true, 1>(g, st)
+                         : launch_8<EPI_BIAS_LNOUT, false, false, true>(g, st);
 #else
         return hipErrorInvalidValue;   // bf16 operands need the separate fp16 residual copy
 #endif
       }
+      if (g.a_tiled)
+        return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true, false, 1>(g, st)
+                                 : launch_8<EPI_BIAS_LNOUT, false, false, false, 1>(g, st);
       return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true>(g, st) : launch_8<EPI_BIAS_LNOUT, false, false>(g, st);
     default: return hipErrorInvalidValue;
   }

@@ -46,6 +46,12 @@ struct GemmArgs {
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
   int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles
   LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr, 0};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
+  // Ping-pong kernel only (engine-internal operands: attention ctx -> attn-out, FFN-up -> FFN-down): the 16-bit
+  // matrix is stored as contiguous 128 x 64 blocks, element (r, c) of an [M, C] matrix at
+  //   (((r >> 7) * (C >> 6) + (c >> 6)) << 13) + ((r & 127) << 6) + (c & 63)      (operand_tiled_offset)
+  // so that each LDS-DMA piece (8 rows x 128 B) is 1 KiB contiguous instead of 8 segments a row apart.
+  bool a_tiled = false;    // A is stored that way (lda must equal K)
+  bool out_tiled = false;  // the 16-bit output is stored that way (ldo must equal N; EPI_BIAS / EPI_BIAS_GELU)
 };
 // ---- launchers that do not depend on the 16-bit operand type (defined once, in the bf16 compile)
 const char* gemm_check(const GemmArgs& g);
@@ -88,7 +94,7 @@ hipError_t launch_mean_loss(const float* row_loss, int n, float* loss, int accum
      by 1/sqrt(64); ctx [T, H].  One workgroup per (128-row q tile, sequence, head). */              \
   static hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx,      \
                                      int n_seqs, int max_seqlen, int n_heads, int hidden,            \
-                                     hipStream_t st);                                                \
+                                     hipStream_t st, bool ctx_tiled = false /* GemmArgs::a_tiled */); \
   /* one q row per sequence (token index focus[s], or the dense q_rows [n_seqs, hidden]):            \
      ctx_rows [n_seqs, H]; sequences up to 512 keys */                                               \
   static hipError_t launch_attention_focus(const bf16_t* qkv, const int32_t* cu_seqlens,             \

@@ -16,7 +16,7 @@ PAT = re.compile(r"(gemm8_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|attention_kernel
 
 
 def key(name):     # as tools/pmc_summary.py: the default SINGLE = false template argument is left out of the key
-    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false>", name)
+    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false(?:, \d+)?>", name)
     return m.group(1) + ">" if m else name
 
 

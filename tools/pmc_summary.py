@@ -12,7 +12,7 @@ PAT = re.compile(r"(gemm8_kernel<[^>]*>|gemm_bf16_kernel<[^>]*>|attention_kernel
 def key(name):
     """gemm8_kernel<EPI, OUT_F32, RES_TILED, SINGLE>: the default SINGLE = false is left out, so the keys of
     earlier summaries (three arguments) stay valid"""
-    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false>", name)
+    m = re.fullmatch(r"(gemm8_kernel<\d+, \w+, \w+), false(?:, \d+)?>", name)
     return m.group(1) + ">" if m else name
 
 
