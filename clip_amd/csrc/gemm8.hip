@@ -170,10 +170,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   };
   auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slices: uniform counts
     char* dst = reinterpret_cast<char*>(bias_lds) + buf * 3072;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + lane * 4), LDS_PTR(dst), 16, 0, 0);
+    // the lane's element offset is made opaque here, so that the three 64-bit lane addresses are formed where they
+    // are used (three adds per tile) instead of being hoisted out of the tile loop: in the fused-LayerNorm kernels,
+    // which sit at 256 registers, they were spilled, and every reload brought an s_waitcnt vmcnt(0) — a drain of
+    // the whole LDS-DMA stream — into the K loop, three times per tile
+    int l4;  // lane id re-derived on the spot (two VALU instructions, no live register across the K loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l4));
+    l4 *= 4;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + l4), LDS_PTR(dst), 16, 0, 0);
     if (EPI == EPI_BIAS_LNRES || EPI == EPI_BIAS_LNOUT) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_gamma + tn_x * BN + lane * 4), LDS_PTR(dst + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_beta + tn_x * BN + lane * 4), LDS_PTR(dst + 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_gamma + tn_x * BN + l4), LDS_PTR(dst + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_beta + tn_x * BN + l4), LDS_PTR(dst + 2048), 16, 0, 0);
     }
   };
 
