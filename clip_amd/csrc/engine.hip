@@ -46,6 +46,10 @@ inline uint16_t host_f32_to_bf16(float f) {
 
 struct LayerW {
   void *wqkv, *wo, *wi, *wo2;  // bf16, or fp32 in check mode
+  // 16-bit settings: the same weights once more as contiguous 128 x 64 blocks (operand_tiled_offset), what the
+  // ping-pong kernel reads (GemmArgs::w_tiled); the row-major ones serve every other kernel.  Null where the shape
+  // does not divide (then the row-major weight is used everywhere).
+  void *wqkv_blk = nullptr, *wo_blk = nullptr, *wo2_blk = nullptr;
   float *bqkv, *bo, *bi, *bo2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 
@@ -151,6 +155,29 @@ int upload_w(clip_engine* e, const float* h, size_t n, void** d, float scale_fir
   std::vector<float> tmp(h, h + n);
   for (size_t i = 0; i < n_first; ++i) tmp[i] *= scale_first;
   return upload_f32(e, tmp, reinterpret_cast<float**>(d));
+}
+
+// dst = src ([N, K] 16-bit, row-major) as contiguous 128 x 64 blocks; once per weight, at load
+__global__ void weight_blocks_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int N, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte chunk (8 elements) each
+  const size_t n_chunks = (size_t)N * K / 8;
+  if (i >= n_chunks) return;
+  const size_t r = i / (K / 8);
+  const int c = (int)(i - r * (K / 8)) * 8;
+  *reinterpret_cast<uint4*>(dst + operand_tiled_offset(r, c, K)) = *reinterpret_cast<const uint4*>(src + r * K + c);
+}
+
+int weight_blocks(clip_engine* e, const void* row_major, size_t N, size_t K, void** blk) {
+  *blk = nullptr;
+  if (e->f32 || N % 128 || K % 64) return CLIP_OK;
+  int rc = dev_alloc(e, blk, N * K * 2);
+  if (rc) return rc;
+  const size_t n_chunks = N * K / 8;
+  hipLaunchKernelGGL(weight_blocks_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0,
+                     static_cast<const uint16_t*>(row_major), static_cast<uint16_t*>(*blk), (int)N, (int)K);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return CLIP_OK;
 }
 
 int alloc_workspace(clip_engine* e) {
@@ -300,11 +327,13 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // f16 setting: operand copy and residual copy would hold the same fp16 bits, so there is ONE: x, row-major,
   // read as the residual and rewritten in place by the fused GEMMs (no xres / xres_rm traffic at all)
   constexpr bool single = std::is_same<KS, k_f16>::value;
-  auto ln_gemm = [&](const void* A, const void* W, const float* bias, int M, int K, const float* gamma,
-                     const float* beta, bool a_tiled) {
+  auto ln_gemm = [&](const void* A, const void* W, const void* W_blk, const float* bias, int M, int K,
+                     const float* gamma, const float* beta, bool a_tiled) {
+    // (A and W in blocks together: the instantiated form; without a block copy of W, A's consumer reads rows)
+    if (a_tiled && W_blk) W = W_blk;
     GemmArgs a{A, W, bias, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres), e->x, M, H, K,
                K, K, H, H, EPI_BIAS_LNOUT, false, 2};
-    a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled;
+    a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled; a.w_tiled = a_tiled;
     a.lnout = LnOutArgs{single ? nullptr : e->xres, !single && !first_res, e->lnpart, e->lnflags, ++e->epoch,
                         c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u};
     first_res = false;
@@ -334,6 +363,10 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // when FFN-up itself runs on the ping-pong kernel (launch_gemm's rule), which alone writes that layout.  The layout
   // moves bytes, not arithmetic: a row's result does not depend on it.
   const bool mid_tiled = fused && (long)(Tg / 256) * (I / 256) >= 256 && I % 256 == 0 && H % 128 == 0;
+  const bool ctx_tiled = fused && e->layers[0].wo_blk != nullptr;
+  // the QKV GEMMs read their weight's block copy when launch_gemm would pick the ping-pong kernel anyway
+  const bool qkv_pp = !f32 && (long)(Tg / 256) * (3 * H / 256) >= 256 && (3 * H) % 256 == 0 && H % 128 == 0;
+  const bool kv_pp = !f32 && (long)(Tg / 256) * (2 * H / 256) >= 256 && (2 * H) % 256 == 0 && H % 128 == 0;
   const bool trim = e->trim_last && c.max_position <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
@@ -345,6 +378,8 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
       g = GemmArgs{e->x, static_cast<bf16_t*>(L.wqkv) + (size_t)H * H, L.bqkv + H, nullptr,
                    static_cast<bf16_t*>(e->qkv) + H, Tg, 2 * H, H, H, H, 3 * H, 0, EPI_BIAS, false};
+      // (rows H.. of the block copy start H / 128 block rows in: the same H * H elements)
+      if (kv_pp && L.wqkv_blk) { g.W = static_cast<bf16_t*>(L.wqkv_blk) + (size_t)H * H; g.w_tiled = true; g.tile = 2; }
       HIP_TRY(KS::launch_gemm(g, st));
       HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
       g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
@@ -354,6 +389,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     {
       ProfScope ps(e, CLIP_KIND_GEMM_QKV, st);
       g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->qkv, Tg, 3 * H, H, H, H, 3 * H, 0, EPI_BIAS, f32, 0, f32};
+      if (qkv_pp && L.wqkv_blk) { g.W = L.wqkv_blk; g.w_tiled = true; g.tile = 2; }
       HIP_TRY(KS::launch_gemm(g, st));
     }
     {
@@ -363,11 +399,11 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
                                      n_seqs, max_seqlen, c.num_heads, H, st));
       else
         HIP_TRY(KS::launch_attention(static_cast<const bf16_t*>(e->qkv), cu, static_cast<bf16_t*>(e->ctx),
-                                 n_seqs, max_seqlen, c.num_heads, H, st, fused));
+                                 n_seqs, max_seqlen, c.num_heads, H, st, ctx_tiled));
     }
     if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
-      HIP_TRY(ln_gemm(e->ctx, L.wo, L.bo, Tg, H, L.ln1g, L.ln1b, true));
+      HIP_TRY(ln_gemm(e->ctx, L.wo, L.wo_blk, L.bo, Tg, H, L.ln1g, L.ln1b, ctx_tiled));
     } else {
       {
         ProfScope ps(e, CLIP_KIND_GEMM_ATTN_OUT, st);
@@ -384,12 +420,12 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_UP, st);
       g = GemmArgs{e->x, L.wi, L.bi, nullptr, e->mid, Tg, I, H, H, H, I, 0, EPI_BIAS_GELU, f32, 0, f32};
-      if (mid_tiled) { g.tile = 2; g.out_tiled = true; }
+      if (mid_tiled && L.wo2_blk) { g.tile = 2; g.out_tiled = true; }
       HIP_TRY(KS::launch_gemm(g, st));
     }
     if (fused) {
       ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
-      HIP_TRY(ln_gemm(e->mid, L.wo2, L.bo2, Tg, I, L.ln2g, L.ln2b, mid_tiled));
+      HIP_TRY(ln_gemm(e->mid, L.wo2, L.wo2_blk, L.bo2, Tg, I, L.ln2g, L.ln2b, mid_tiled && L.wo2_blk));
     } else {
       {
         ProfScope ps(e, CLIP_KIND_GEMM_FFN_DOWN, st);
@@ -629,6 +665,7 @@ int clip_finalize_weights(clip_engine* e) {
       bqkv[2 * H + j] = (*bv)[j];
     }
     if ((rc = upload_w(e, wqkv.data(), wqkv.size(), &L.wqkv, 0.125f, H * H))) return rc;
+    if ((rc = weight_blocks(e, L.wqkv, 3 * H, H, &L.wqkv_blk))) return rc;
     if ((rc = upload_f32(e, bqkv, &L.bqkv))) return rc;
     GET(wo, p + "attention.output.dense.weight", H * H);
     GET(bo, p + "attention.output.dense.bias", H);
@@ -646,6 +683,7 @@ int clip_finalize_weights(clip_engine* e) {
         (rc = upload_w(e, w2->data(), w2->size(), &L.wo2)) || (rc = upload_f32(e, *b2, &L.bo2)) ||
         (rc = upload_f32(e, *g2, &L.ln2g)) || (rc = upload_f32(e, *bb2, &L.ln2b)))
       return rc;
+    if ((rc = weight_blocks(e, L.wo, H, H, &L.wo_blk)) || (rc = weight_blocks(e, L.wo2, H, I, &L.wo2_blk))) return rc;
   }
   {
     GET(wc, "classifier.weight", (size_t)c.num_labels * H);

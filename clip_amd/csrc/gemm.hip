@@ -341,7 +341,7 @@ hipError_t KSET::launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.f32_in) return hipErrorInvalidValue;  // the fp32 check mode lives in the bf16 set
 #endif
   if (g.res_index && g.tile == 2) return hipErrorInvalidValue;
-  if ((g.a_tiled || g.out_tiled) && g.tile != 2) return hipErrorInvalidValue;  // block layouts: ping-pong kernel only
+  if ((g.a_tiled || g.out_tiled || g.w_tiled) && g.tile != 2) return hipErrorInvalidValue;  // block layouts: ping-pong kernel only
   if (g.tile == 2 || (g.tile == 0 && gemm_persist_ok(g) && (long)(g.M / 256) * (g.N / 256) >= 256 &&
                       !((g.epi == EPI_BIAS_TANH || g.epi == EPI_BIAS_GELU) && g.out_f32) && !g.res_index &&
                       g.epi != EPI_BIAS_RES16))

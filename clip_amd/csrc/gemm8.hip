@@ -99,7 +99,8 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // next GEMM's operand AND as the next residual (in the f16 setting the two copies of the bf16 setting hold the
 // same bits); the residual is then read from the row-major buffer this tile rewrites in place (every wave reads
 // exactly the 64 x 64 blocks it writes).
-// LAYOUT bit 0: A, bit 1: the 16-bit output, stored as contiguous 128 x 64 blocks (GemmArgs::a_tiled / out_tiled)
+// LAYOUT bit 0: A, bit 1: the 16-bit output, bit 2: W, stored as contiguous 128 x 64 blocks (GemmArgs::a_tiled /
+// out_tiled / w_tiled)
 template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false, int LAYOUT = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -162,7 +163,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   const int ld_a = a_tiled ? 64 : lda, a_kstep = a_tiled ? 8192 : BK;
   const size_t a_half = a_tiled ? (size_t)(K >> 6) * 8192 : (size_t)128 * lda;   // rows 128.. of the tile
   const size_t a_panel = a_tiled ? (size_t)BM * K : (size_t)BM * lda;
-  const int a_off = prow * ld_a + pchunk, w_off = prow * ldw + pchunk;
+  constexpr bool w_tiled = (LAYOUT & 4) != 0;
+  const int ld_w = w_tiled ? 64 : ldw, w_kstep = w_tiled ? 8192 : BK;
+  const size_t w_half = w_tiled ? (size_t)(K >> 6) * 8192 : (size_t)128 * ldw;
+  const size_t w_panel = w_tiled ? (size_t)BN * K : (size_t)BN * ldw;
+  const int a_off = prow * ld_a + pchunk, w_off = prow * ld_w + pchunk;
   auto stage_half = [&](const bf16_t* src, int off, int ld, int slot_idx) {
     char* dst = smem + slot_idx * HT + w * 1024;
     __builtin_amdgcn_global_load_lds(GLB_PTR(src + off), LDS_PTR(dst), 16, 0, 0);
@@ -203,27 +208,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       v2 = tile_at(s_it, s_tm, s_tn);
       if (!v2) return;
       a2 = A + (size_t)s_tm * a_panel;
-      w2 = W + (size_t)s_tn * BN * ldw;
+      w2 = W + (size_t)s_tn * w_panel;
     } else {
       a2 += a_kstep;
-      w2 += BK;
+      w2 += w_kstep;
     }
   };
 
   // ---- prologue: K tile 0 whole, the bias slice, three half-tiles of K tile 1
   {
     const bf16_t* a0 = A + (size_t)tm * a_panel;
-    const bf16_t* w0 = W + (size_t)tn * BN * ldw;
+    const bf16_t* w0 = W + (size_t)tn * w_panel;
     stage_half(a0, a_off, ld_a, 0);
-    stage_half(w0, w_off, ldw, 1);
-    stage_half(w0 + (size_t)128 * ldw, w_off, ldw, 2);
+    stage_half(w0, w_off, ld_w, 1);
+    stage_half(w0 + w_half, w_off, ld_w, 2);
     stage_half(a0 + a_half, a_off, ld_a, 3);
     stage_bias(tn, 0);
     a2 = a0; w2 = w0; v2 = true;
     advance();  // c2 = K tile 1
     advance();  // c1 = K tile 1, c2 = K tile 2 (or the next tile's first)
     stage_half(a1, a_off, ld_a, 4);
-    stage_half(w1, w_off, ldw, 5);
+    stage_half(w1, w_off, ld_w, 5);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
           bf1[i][1] = *reinterpret_cast<const opx8_t*>(buf + b_rd + 4096 + i * 2048 + c1);
         }
         if (v1) {
-          stage_half(w1 + (size_t)128 * ldw, w_off, ldw, (B ^ 1) * 4 + 2);
+          stage_half(w1 + w_half, w_off, ld_w, (B ^ 1) * 4 + 2);
           if (GEMM8_SPLIT == 0) stage_half(a1 + a_half, a_off, ld_a, (B ^ 1) * 4 + 3);
           // in flight behind this wait: (t+1).A0/B0 from the previous phase and the four just issued;
           // (t).A1, read next phase, is older
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
         const bf16_t* w2_mid = w2;  // (GEMM8_SPLIT: the W half staged mid-block, after advance() moved the cursor)
         if (v2) {
           stage_half(a2, a_off, ld_a, B * 4 + 0);
-          if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ldw, B * 4 + 1);
+          if (GEMM8_SPLIT == 0) stage_half(w2, w_off, ld_w, B * 4 + 1);
         }
         advance();
         if (staged2) {
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
             }
           if (GEMM8_SPLIT == 1 && ks == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (staged2) stage_half(w2_mid, w_off, ldw, B * 4 + 1);
+            if (staged2) stage_half(w2_mid, w_off, ld_w, B * 4 + 1);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -741,10 +746,14 @@ hipError_t launch_8(const GemmArgs& g, hipStream_t st) {
 hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
   if (!gemm_persist_ok(g) || g.res_index) return hipErrorInvalidValue;
   // block layouts: the engine's two single-reader operands only (attention ctx / FFN intermediate -> LayerNorm GEMMs)
-  if (g.a_tiled && (g.lda != g.K || g.epi != EPI_BIAS_LNOUT)) return hipErrorInvalidValue;
-  if (g.out_tiled && (g.ldo != g.N || g.out_f32 || g.a_tiled || g.epi != EPI_BIAS_GELU)) return hipErrorInvalidValue;
+  if (g.a_tiled && (g.lda != g.K || g.epi != EPI_BIAS_LNOUT || !g.w_tiled)) return hipErrorInvalidValue;
+  if (g.out_tiled && (g.ldo != g.N || g.out_f32 || g.a_tiled || g.w_tiled || g.epi != EPI_BIAS_GELU)) return hipErrorInvalidValue;
+  if (g.w_tiled && (g.ldw != g.K || g.out_f32 || (g.epi != EPI_BIAS_LNOUT && g.epi != EPI_BIAS) ||
+                    (g.epi == EPI_BIAS_LNOUT && !g.a_tiled)))
+    return hipErrorInvalidValue;   // (the instantiated forms: QKV with W in blocks, LayerNorm GEMMs with A and W in blocks)
   switch (g.epi * 2 + (g.out_f32 ? 1 : 0)) {
-    case EPI_BIAS * 2 + 0: return launch_8<EPI_BIAS, false>(g, st);
+    case EPI_BIAS * 2 + 0:
+      return g.w_tiled ? launch_8<EPI_BIAS, false, false, false, 4>(g, st) : launch_8<EPI_BIAS, false>(g, st);
     case EPI_BIAS * 2 + 1: return launch_8<EPI_BIAS, true>(g, st);
     case EPI_BIAS_GELU * 2 + 0:
       return g.out_tiled ? launch_8<EPI_BIAS_GELU, false, false, false, 2>(g, st) : launch_8<EPI_BIAS_GELU, false>(g, st);
@@ -758,15 +767,15 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
 #if CLIP_OPERAND_F16
         // one copy: operand = residual (fp16), read row-major from the buffer the tile rewrites
         if (g.lnout.res_tiled || g.res != g.out || g.ldres != g.ldo) return hipErrorInvalidValue;
-        return g.a_tiled ? launch_8<EPI_BIAS_LNOUT, false, false, true, 1>(g, st)
+        return g.a_tiled ? launch_8<EPI_BIAS_LNOUT, false, false, true, 5>(g, st)
                          : launch_8<EPI_BIAS_LNOUT, false, false, true>(g, st);
 #else
         return hipErrorInvalidValue;   // bf16 operands need the separate fp16 residual copy
 #endif
       }
       if (g.a_tiled)
-        return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true, false, 1>(g, st)
-                                 : launch_8<EPI_BIAS_LNOUT, false, false, false, 1>(g, st);
+        return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true, false, 5>(g, st)
+                                 : launch_8<EPI_BIAS_LNOUT, false, false, false, 5>(g, st);
       return g.lnout.res_tiled ? launch_8<EPI_BIAS_LNOUT, false, true>(g, st) : launch_8<EPI_BIAS_LNOUT, false, false>(g, st);
     default: return hipErrorInvalidValue;
   }

@@ -52,6 +52,7 @@ struct GemmArgs {
   // so that each LDS-DMA piece (8 rows x 128 B) is 1 KiB contiguous instead of 8 segments a row apart.
   bool a_tiled = false;    // A is stored that way (lda must equal K)
   bool out_tiled = false;  // the 16-bit output is stored that way (ldo must equal N; EPI_BIAS / EPI_BIAS_GELU)
+  bool w_tiled = false;    // W is stored that way (a copy made once when the weights are loaded; ldw must equal K)
 };
 // ---- launchers that do not depend on the 16-bit operand type (defined once, in the bf16 compile)
 const char* gemm_check(const GemmArgs& g);
