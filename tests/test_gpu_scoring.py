@@ -118,3 +118,23 @@ def test_bulk_scorer_edge_inputs(golden):
         small.score([g["rows"][-1]])                                   # a 512-token row cannot fit a 64-token step
     with pytest.raises(ValueError):
         scoring.BulkScorer(model, tokens_per_step=4096)                # beyond the engine's workspace
+
+
+def test_step_size_and_operand_layouts_do_not_change_a_bit():
+    """BERT-base, the same 420 ragged rows scored in steps of 2 048, 6 144 and 32 768 tokens.  The engine picks its
+    kernels and operand layouts by the step's size — small steps: one-tile GEMMs, row-major operands; 6 144 tokens:
+    the ping-pong kernel for the FFN with the intermediate as 128 x 64 blocks; 32 768: also the QKV GEMM on the
+    block copy of its weight — and a row's scores must not depend on any of it (engine.hip: "the layout moves bytes,
+    not arithmetic"; the reference scores a sentence the same whatever batch it lands in)."""
+    from clip_amd.config import BertConfig
+    cfg = BertConfig()
+    rows = synth.context_rows(420, 2, cfg.vocab_size, max_len=256, seed=77, sigma=0.7, seg_hi=80)
+    assert sum(len(r) for r in rows) > 34000
+    model = _model(cfg, 5, 2, max_tokens=32768, max_seqs=1024)
+    outs = []
+    for tokens in (2048, 6144, 32768):
+        res = scoring.BulkScorer(model, keep_probs=True, tokens_per_step=tokens).score(rows)
+        outs.append(res.probs.copy())
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    model._drop_engine()
