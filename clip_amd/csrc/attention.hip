@@ -16,6 +16,9 @@
 
 namespace {
 
+#ifndef ATTN_DMA
+#define ATTN_DMA 1          // 0: K/V tiles through registers and ds_write (diagnostic builds)
+#endif
 #ifndef ATTN_PAIR
 #define ATTN_PAIR 1          // 0: diagnostic builds with the 2-D grid for every launch
 #endif
@@ -52,8 +55,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                         const int32_t* __restrict__ cu,
                                                         bf16_t* __restrict__ ctx, int hidden,
                                                         int q_tiles, int n_heads, int n_pairs, int ctx_tiled) {
-  __shared__ __attribute__((aligned(16))) char k_lds[KT * 128];
-  __shared__ __attribute__((aligned(16))) char v_lds[KT * 128];
+  // DMA (launches whose sequences span several key tiles per q tile, i.e. not KV_ONCE): two K/V tile buffers filled by
+  // LDS-DMA, [buffer][k | v][64 keys x 128 B]; otherwise one buffer filled through registers.  Measured per length
+  // (bench.py, alternating processes, DMA against registers): L = 32 + 10 %, 64 and 128 equal, 256 - 2 %, 512 - 6.5 %.
+  constexpr bool DMA = ATTN_DMA && !KV_ONCE;
+  __shared__ __attribute__((aligned(16))) char kv_lds[(DMA ? 2 : 1) * 2 * KT * 128];
 
   int seq, head, qt;
   if (n_pairs > 0) {
@@ -97,7 +103,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       qf[s] = *reinterpret_cast<const opx8_t*>(qbase + (size_t)qr * ld + 16 * s + 8 * h);
   }
 
-  // staging map: thread -> (row, chunk) for two 16-B chunks of K and of V per tile
+  // K/V tile t -> buffer t & 1 by LDS-DMA: wave w writes the 1-KiB images of rows 8 w .. 8 w + 7 and 32 + 8 w .. of k and
+  // of v (lane-linear: lane l lands at row l >> 3, 16-byte slot l & 7), so the swizzle is applied to the SOURCE chunk
+  // each lane fetches (both swizzles are XORs: slot = chunk ^ f(row) <=> chunk = slot ^ f(row)).  Keys past the end
+  // fetch the sequence's last row: finite values, masked below.  No staging registers, no ds_write, one barrier per tile.
+  auto stage_tile = [&](int kv0, int b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rl = w * 8 + (lane >> 3) + 32 * i;     // row inside the tile
+      const int r = min(kv0 + rl, len - 1);
+      const int slot = lane & 7;
+      // Issued as inline assembly: through the builtin the compiler tracks "an LDS-DMA store to kv_lds is outstanding"
+      // per ARRAY, not per buffer, and puts s_waitcnt vmcnt(0) in front of the first transposed V read of the tile
+      // being computed — i.e. makes the tile wait for the NEXT tile's loads.  Hidden loads can only make its own
+      // counted waits wait longer, never shorter (in-order counter); the waits these loads need are written out below.
+      const uint32_t kd = (uint32_t)(uintptr_t)LDS_PTR(kv_lds + b * (2 * KT * 128) + (w + 4 * i) * 1024);
+      const bf16_t* kg = kbase + (size_t)r * ld + (slot ^ ((rl >> 1) & 7)) * 8;
+      const bf16_t* vg = vbase + (size_t)r * ld + (slot ^ (((rl >> 1) & 1) << 2)) * 8;
+      // (m0 = the LDS address of the wave's 1-KiB image; the compiler reserves m0 and says so — nothing else in this
+      // kernel uses it: no other LDS-DMA, no GWS, no movrel)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      if (KV_ONCE) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(kg), "s"(kd) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(vg), "s"(kd + KT * 128) : "memory", "m0");
+      } else {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(kg), "s"(kd) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vg), "s"(kd + KT * 128) : "memory", "m0");
+      }
+#pragma clang diagnostic pop
+    }
+  };
+  // (registers) staging map: thread -> (row, chunk) for two 16-B chunks of K and of V per tile
   const int st_row = tid >> 3, st_chunk = tid & 7;  // rows st_row and st_row + 32
   uint4 kreg[2], vreg[2];
   auto load_tile = [&](int kv0) {
@@ -125,8 +162,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = st_row + 32 * i;
-      *reinterpret_cast<uint4*>(k_lds + r * 128 + swz128(r, st_chunk) * 16) = kreg[i];
-      *reinterpret_cast<uint4*>(v_lds + r * 128 + swz_v(r, st_chunk) * 16) = vreg[i];
+      *reinterpret_cast<uint4*>(kv_lds + r * 128 + swz128(r, st_chunk) * 16) = kreg[i];
+      *reinterpret_cast<uint4*>(kv_lds + KT * 128 + r * 128 + swz_v(r, st_chunk) * 16) = vreg[i];
     }
   };
 
@@ -138,15 +175,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float m_run = -INFINITY, l_run = 0.f;  // running max (log2 domain, shared by both halves), partial sum
 
   const int n_tiles = (len + KT - 1) / KT;
-  load_tile(0);
+  if constexpr (DMA) {
+    stage_tile(0, 0);
+    // the Q fragments are pinned here: left alone, the compiler waits for them at their first use INSIDE the loop with
+    // counted waits that, not knowing of the hidden LDS-DMA loads, would drain the next tile's loads in every iteration
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(qf[s]));
+  } else {
+    load_tile(0);
+  }
   A_STAMP(1)
   for (int t = 0; t < n_tiles; ++t) {
     A_STAMP_T(2)
-    __syncthreads();  // previous tile's LDS reads done
-    store_tile();
-    __syncthreads();
-    A_STAMP_T(3)
-    if (t + 1 < n_tiles) load_tile((t + 1) * KT);
+    const char* k_lds = kv_lds;
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed ...
+      __syncthreads();                                   // ... every wave's have, and tile t - 1 has been read by all
+      A_STAMP_T(3)
+      if (t + 1 < n_tiles) stage_tile((t + 1) * KT, (t + 1) & 1);
+      k_lds = kv_lds + (t & 1) * (2 * KT * 128);
+    } else {
+      __syncthreads();  // previous tile's LDS reads done
+      store_tile();
+      __syncthreads();
+      A_STAMP_T(3)
+      if (t + 1 < n_tiles) load_tile((t + 1) * KT);
+    }
+    const char* v_lds = k_lds + KT * 128;
     A_STAMP_T(4)
     if (!wave_live) continue;
 
@@ -245,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (!wave_live) return;
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_run;
-  char* ot = (w < 2 ? k_lds : v_lds) + (w & 1) * 4096;   // [32 q rows][128 B], 8-byte slots XOR-swizzled in pairs
+  char* ot = kv_lds + w * 4096;   // [32 q rows][128 B], 8-byte slots XOR-swizzled in pairs (no DMA in flight any more)
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
