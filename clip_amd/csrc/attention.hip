@@ -8,9 +8,13 @@
 // Per 64-key tile:  S^T = K Q^T  (32x32x16 MFMA, key on rows, q on the lane -> a q row's softmax
 // statistics are lane-local), P = exp2(S^T - m) converted in place to the B operand of
 // O^T = V^T P^T (the accumulator-as-operand k order of the guide, §3), V^T fragments come from
-// the row-major V tile in LDS through ds_read_b64_tr_b16.  K/V tiles are register-staged
-// (next tile's global loads are issued before the current tile's MFMAs, written to LDS after
-// the barrier), K swizzled for ds_read_b128, V swizzled for the transposed read.
+// the row-major V tile in LDS through ds_read_b64_tr_b16.  K swizzled for ds_read_b128, V swizzled
+// for the transposed read.  K/V tiles reach LDS in one of two ways, chosen per launch:
+//   attention_kernel<false> (sequences of several key tiles per q tile): by LDS-DMA into two tile
+//     buffers — the next tile's loads are issued right after the barrier that hands over the current
+//     one, no staging registers, no ds_write, one barrier per tile;
+//   attention_kernel<true>  (max_seqlen <= 128, nothing to overlap): through registers, the next
+//     tile's global loads issued before the current tile's MFMAs and written to LDS after a barrier.
 #include "common.h"
 #include "kernels.h"
 
