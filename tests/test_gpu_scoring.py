@@ -120,7 +120,8 @@ def test_bulk_scorer_edge_inputs(golden):
         scoring.BulkScorer(model, tokens_per_step=4096)                # beyond the engine's workspace
 
 
-def test_step_size_and_operand_layouts_do_not_change_a_bit():
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_step_size_and_operand_layouts_do_not_change_a_bit(precision):
     """BERT-base, the same 420 ragged rows scored in steps of 2 048, 6 144 and 32 768 tokens.  The engine picks its
     kernels and operand layouts by the step's size — small steps: one-tile GEMMs, row-major operands; 6 144 tokens:
     the ping-pong kernel for the FFN with the intermediate as 128 x 64 blocks; 32 768: also the QKV GEMM on the
@@ -130,7 +131,13 @@ def test_step_size_and_operand_layouts_do_not_change_a_bit():
     cfg = BertConfig()
     rows = synth.context_rows(420, 2, cfg.vocab_size, max_len=256, seed=77, sigma=0.7, seg_hi=80)
     assert sum(len(r) for r in rows) > 34000
-    model = _model(cfg, 5, 2, max_tokens=32768, max_seqs=1024)
+    model = args_to_model(2)(cfg, max_tokens=32768, max_seqs=1024)
+    model.set_precision(precision)
+    model.load_state_dict(procedural_state_dict(cfg, 5))
+    model.to("cuda").eval()
+    model.set_sep_token_id(102)
+    model.set_n_context_sentences(2)
+    model.set_task("multilabel")
     outs = []
     for tokens in (2048, 6144, 32768):
         res = scoring.BulkScorer(model, keep_probs=True, tokens_per_step=tokens).score(rows)
