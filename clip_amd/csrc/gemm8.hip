@@ -168,10 +168,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
   const size_t w_half = w_tiled ? (size_t)(K >> 6) * 8192 : (size_t)128 * ldw;
   const size_t w_panel = w_tiled ? (size_t)BN * K : (size_t)BN * ldw;
   const int a_off = prow * ld_a + pchunk, w_off = prow * ld_w + pchunk;
+  // The LDS-DMA loads are issued as inline assembly (m0 = LDS address of the wave's 1-KiB image).  Through the builtin
+  // the compiler knows that LDS-DMA stores into `smem` are outstanding and, tracking them per array, puts
+  // s_waitcnt vmcnt(0) in front of the epilogue's first LDS access (the per-wave scratch lives in the same array):
+  // every epilogue then began by draining the half-tiles staged for the NEXT tile.  Hidden loads can only make the
+  // compiler's own counted waits wait longer, never shorter (one in-order counter); every wait the DMA stream
+  // needs is written out in this file.  (QKV - 0.7 %, FFN-up - 0.5 % in alternating bench.py processes.)
+  auto dma16 = [&](const void* g, const char* lds_dst) {
+    if (EPI == EPI_BIAS_LNOUT) {   // (the fused-LayerNorm kernels measured 0.5 % slower with the hidden form: builtin kept)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_dst), 16, 0, 0);
+      return;
+    }
+    const uint32_t m = (uint32_t)(uintptr_t)LDS_PTR(lds_dst);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // "m0 is reserved": nothing else in this kernel uses it
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
   auto stage_half = [&](const bf16_t* src, int off, int ld, int slot_idx) {
     char* dst = smem + slot_idx * HT + w * 1024;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src + off), LDS_PTR(dst), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(src + off + 64 * ld), LDS_PTR(dst + 8192), 16, 0, 0);
+    dma16(src + off, dst);
+    dma16(src + off + 64 * ld, dst + 8192);
   };
   auto stage_bias = [&](int tn_x, int buf) {  // every wave fetches the whole 1-KiB slices: uniform counts
     char* dst = reinterpret_cast<char*>(bias_lds) + buf * 3072;
@@ -182,10 +199,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
     int l4;  // lane id re-derived on the spot (two VALU instructions, no live register across the K loop)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l4));
     l4 *= 4;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(bias + tn_x * BN + l4), LDS_PTR(dst), 16, 0, 0);
+    dma16(bias + tn_x * BN + l4, dst);
     if (EPI == EPI_BIAS_LNRES || EPI == EPI_BIAS_LNOUT) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_gamma + tn_x * BN + l4), LDS_PTR(dst + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ln_beta + tn_x * BN + l4), LDS_PTR(dst + 2048), 16, 0, 0);
+      dma16(ln_gamma + tn_x * BN + l4, dst + 1024);
+      dma16(ln_beta + tn_x * BN + l4, dst + 2048);
     }
   };
 
