@@ -98,6 +98,7 @@ struct clip_engine {
   int mlm_cap = 0;
   hipStream_t last_stream = nullptr;  // stream of the latest forward: clip_poll_errors reads behind it
   bool test_drop = false;             // CLIP_AMD_TEST_DROP_PUBLISH=1 (tests): one fused-LayerNorm tile never publishes
+  size_t ln_tiles = 0;                // entries of lnflags
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -212,6 +213,7 @@ int alloc_workspace(clip_engine* e) {
   }
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
+  e->ln_tiles = n_tiles;
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   if (rc) return rc;
   if (two_copies) {
@@ -334,6 +336,13 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     GemmArgs a{A, W, bias, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres), e->x, M, H, K,
                K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled; a.w_tiled = a_tiled;
+    if (e->epoch == 0xffffffffu) {
+      // 2^32 launches on these flags (weeks of continuous scoring): a stale flag could equal a new epoch and let a
+      // tile run ahead of its partners.  Clear the flags (stream-ordered behind every earlier launch) and start over.
+      const hipError_t er = hipMemsetAsync(e->lnflags, 0, e->ln_tiles * 4, st);
+      if (er != hipSuccess) return er;
+      e->epoch = 0;
+    }
     a.lnout = LnOutArgs{single ? nullptr : e->xres, !single && !first_res, e->lnpart, e->lnflags, ++e->epoch,
                         c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u};
     first_res = false;
@@ -585,6 +594,7 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   e->cfg = *c;
   e->device = device_id;
   if (const char* t = getenv("CLIP_AMD_TEST_DROP_PUBLISH")) e->test_drop = t[0] == '1';
+  if (const char* t = getenv("CLIP_AMD_TEST_EPOCH_START")) e->epoch = (uint32_t)strtoul(t, nullptr, 0);  // (tests: epoch wrap)
   *out = e;
   return CLIP_OK;
 }

@@ -236,3 +236,31 @@ def test_fused_layernorm_timeout_is_loud(monkeypatch):
     with pytest.raises(RuntimeError, match="timed out"):
         model(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda())
     model._drop_engine()
+
+
+def test_fused_layernorm_epoch_wrap_is_handled(monkeypatch):
+    """The fused-LayerNorm exchange recognises a partner's statistics by the launch's epoch, a 32-bit counter per
+    engine.  An engine whose counter starts a few launches below 2^32 (diagnostic switch CLIP_AMD_TEST_EPOCH_START)
+    must score exactly like a fresh one: at the wrap the flags are cleared and the epochs start over."""
+    from clip_amd import scoring, synth
+    from clip_amd.bert_model import BertSequenceMultilabelClassificationContext
+    from clip_amd.config import BertConfig
+    from clip_amd.weights import procedural_state_dict
+    cfg = BertConfig(vocab_size=2000, hidden_size=512, num_hidden_layers=3, num_attention_heads=8, intermediate_size=1024)
+    rows = synth.context_rows(300, 2, cfg.vocab_size, max_len=96, seed=12)
+    outs = []
+    for start in (None, str(0xffffffff - 7)):      # 6 fused GEMMs per step, a few steps: the wrap falls inside
+        if start is None:
+            monkeypatch.delenv("CLIP_AMD_TEST_EPOCH_START", raising=False)
+        else:
+            monkeypatch.setenv("CLIP_AMD_TEST_EPOCH_START", start)
+        model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=8192, max_seqs=512)
+        model.load_state_dict(procedural_state_dict(cfg, 3))
+        model.to("cuda").eval()
+        model.set_sep_token_id(102); model.set_n_context_sentences(2); model.set_task("multilabel")
+        res = scoring.BulkScorer(model, keep_probs=True, tokens_per_step=4096).score(rows)
+        res2 = scoring.BulkScorer(model, keep_probs=True, tokens_per_step=4096).score(rows)
+        assert np.array_equal(res.probs, res2.probs)
+        outs.append(res.probs.copy())
+        model._drop_engine()
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
