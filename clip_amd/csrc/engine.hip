@@ -365,8 +365,6 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
   const int Tg = f32 ? T : (T + 255) / 256 * 256;
-  // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
-  // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
   // Fused flow: the two operands with ONE writer and ONE reader — attention's ctx (-> attn-out) and the FFN
   // intermediate (-> FFN-down) — are kept as contiguous 128 x 64 blocks (GemmArgs::a_tiled); the intermediate only
   // when FFN-up itself runs on the ping-pong kernel (launch_gemm's rule), which alone writes that layout.  The layout
@@ -376,6 +374,8 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // the QKV GEMMs read their weight's block copy when launch_gemm would pick the ping-pong kernel anyway
   const bool qkv_pp = !f32 && (long)(Tg / 256) * (3 * H / 256) >= 256 && (3 * H) % 256 == 0 && H % 128 == 0;
   const bool kv_pp = !f32 && (long)(Tg / 256) * (2 * H / 256) >= 256 && (2 * H) % 256 == 0 && H % 128 == 0;
+  // the focus-row kernels of the trimmed last layer are bf16 only: check mode runs every layer whole
+  // (decided by the engine's geometry, never by the batch: a row's logits must not depend on its step)
   const bool trim = e->trim_last && c.max_position <= 512 && !f32;
   for (int i = 0; i < c.num_layers; ++i) {
     const LayerW& L = e->layers[i];
