@@ -335,7 +335,8 @@ class BertContextMLMSwitch(BertSequenceMultilabelClassificationContext):
         scores = None
         if mlm_labels is not None:
             lib, h = _lib.load(), self._ensure_engine()
-            rows, labs = self._mlm_rows(mlm_labels.to(self.device), attention_mask)
+            rows, labs = self._mlm_rows(mlm_labels.to(self.device),
+                                        None if attention_mask is None else attention_mask.to(self.device))
             n = rows.numel()
             loss = torch.zeros(1, dtype=torch.float32, device=self.device)
             if return_mlm_scores:
@@ -345,9 +346,16 @@ class BertContextMLMSwitch(BertSequenceMultilabelClassificationContext):
                                              _lib.stream_ptr()))
                 if labels is not None:                              # + switch loss (bert_model.py:180-183)
                     lab = labels.to(self.device).reshape(-1).to(torch.int32).contiguous()
-                    row_loss = torch.empty(lab.numel(), dtype=torch.float32, device=self.device)
-                    _lib.check(lib.clip_ce_loss(_lib.ptr(logits), _lib.ptr(lab), lab.numel(), self.num_labels,
-                                                _lib.ptr(row_loss), _lib.ptr(loss), 1, _lib.stream_ptr()))
+                    sw_logits = logits
+                    if bool((lab == -100).any()):   # CrossEntropyLoss ignores -100 here too (bert_model.py:177-183)
+                        keep = lab != -100
+                        lab, sw_logits = lab[keep].contiguous(), logits[keep].contiguous()
+                    if lab.numel() == 0:
+                        loss += float("nan")        # torch: the mean over zero rows
+                    else:
+                        row_loss = torch.empty(lab.numel(), dtype=torch.float32, device=self.device)
+                        _lib.check(lib.clip_ce_loss(_lib.ptr(sw_logits), _lib.ptr(lab), lab.numel(), self.num_labels,
+                                                    _lib.ptr(row_loss), _lib.ptr(loss), 1, _lib.stream_ptr()))
             outputs = (loss[0],) + outputs
         return outputs + ((scores,) if return_mlm_scores else ())
 

@@ -260,7 +260,7 @@ constexpr size_t SCRATCH_BYTES = SCRATCH_FLAGS_OFF + (size_t)CLIP_NOALLOC_MAX_TI
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
 namespace {
-struct ScratchDev { unsigned char* ptr = nullptr; uint32_t epoch = 0; };
+struct ScratchDev { unsigned char* ptr = nullptr; };
 ScratchDev g_scratch_dev[64];
 std::mutex g_scratch_mu;
 
@@ -944,28 +944,26 @@ int clip_gemm_bf16_lnout_noalloc(const uint16_t* A, const uint16_t* W, const flo
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return fail(CLIP_ERR_ARG, "clip_gemm_bf16_lnout_noalloc: device %d", dev);
   hipStream_t st = (hipStream_t)stream;
-  uint32_t epoch;
   unsigned char* base;
   {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     ScratchDev& sd = g_scratch_dev[dev];
-    bool clear = false;
     if (!sd.ptr) {
       // once per device, with that device current: the device address of THIS GPU's copy of the array
       // (the array's name is a host-side stand-in, never a kernel argument)
       void* p = nullptr;
       HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
       sd.ptr = static_cast<unsigned char*>(p);
-      clear = true;
     }
-    if (++sd.epoch == 0) { sd.epoch = 1; clear = true; }  // epoch wrap: stale flags could match again
     base = sd.ptr;
-    epoch = sd.epoch;
-    // the flags must start below every epoch (the array keeps the last call's contents otherwise)
-    if (clear) HIP_TRY(hipMemsetAsync(base + SCRATCH_FLAGS_OFF, 0, (size_t)CLIP_NOALLOC_MAX_TILES * 4, st));
   }
+  // The array keeps the last call's contents, so EVERY call clears the flags of the tiles it will use, on
+  // `stream`, ahead of its kernel, and the kernel waits for the constant value 1.  No host-side counter is
+  // baked into the kernel arguments: a call recorded into a HIP graph (memset node + kernel node) replays
+  // correctly any number of times.
+  HIP_TRY(hipMemsetAsync(base + SCRATCH_FLAGS_OFF, 0, (size_t)tiles * 4, st));
   g.lnout = LnOutArgs{xres_out, res_tiled != 0, reinterpret_cast<float*>(base),
-                      reinterpret_cast<uint32_t*>(base + SCRATCH_FLAGS_OFF), epoch, eps, err, 0};
+                      reinterpret_cast<uint32_t*>(base + SCRATCH_FLAGS_OFF), 1u, eps, err, 0};
   HIP_TRY(k_bf16::launch_gemm(g, st));
   return CLIP_OK;
 }

@@ -188,7 +188,15 @@ class BulkScorer:
             res[order] = a
             return res
 
-        return ScoreResult(doc_ids=doc_ids, sent_ixs=sent_ixs, max_score=unsort(out_max),
+        max_score = unsort(out_max)
+        bad = int(np.count_nonzero(~np.isfinite(max_score)))
+        if bad:
+            # fp16 operands overflow to inf -> NaN logits -> `p > thr` False: the sentence would silently drop out of
+            # ttp_doc_sents.csv and the top-k file.  (A device error word would have raised in poll_errors above.)
+            raise FloatingPointError(f"{bad} of {N} sentences scored non-finite in precision {model.precision!r}: "
+                                     "an activation left the operand type's range (f16: use 'bf16' or 'fp32' for "
+                                     "this checkpoint)")
+        return ScoreResult(doc_ids=doc_ids, sent_ixs=sent_ixs, max_score=max_score,
                            keep=unsort(out_keep).astype(bool),
                            labels=None if out_lab is None else unsort(out_lab).astype(bool),
                            probs=None if out_p is None else unsort(out_p))

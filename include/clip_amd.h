@@ -197,12 +197,16 @@ int clip_gemm_f16_lnout_inplace(const uint16_t* dev_A, const uint16_t* dev_W, co
 /* clip_gemm_bf16_lnout for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, kernel and
  * result bits as clip_gemm_bf16_lnout, minus dev_part / dev_flags / epoch: the exchange buffers live in
- * a static device array inside the library (4.2 MB per GPU, held until the process ends) and the
- * epoch is kept per device by the library.  Calls no hipMalloc / hipFree or allocating routine; the first
- * call on a device resolves the array's address (hipGetSymbolAddress) and clears its flags on `stream`.
+ * a static device array inside the library (4.2 MB per GPU, held until the process ends).  Calls no
+ * hipMalloc / hipFree or allocating routine.  Every call enqueues, on `stream`, a clear of the flags of the
+ * tiles it uses followed by the kernel (which waits for the constant 1): nothing in the kernel arguments
+ * depends on a host-side counter, so a call recorded into a HIP graph replays correctly any number of
+ * times (tests/test_zz_no_alloc.py captures one call and replays it on changed inputs).  The FIRST call on
+ * a device resolves the array's address (hipGetSymbolAddress) and the kernel's launch attributes: make
+ * one eager call per device before capturing.
  * Limit: (M/256)*(N/256) <= CLIP_NOALLOC_MAX_TILES, else CLIP_ERR_CAPACITY.  All calls on one GPU share
- * that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race on it —
- * serialise them; calls on different GPUs are independent.  Runs on the current device. */
+ * that GPU's array: calls that overlap in time on one GPU (two streams, two threads, two graphs in
+ * flight) race on it — serialise them; calls on different GPUs are independent.  Runs on the current device. */
 #define CLIP_NOALLOC_MAX_TILES 2048
 int clip_gemm_bf16_lnout_noalloc(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
                                  const uint16_t* dev_res16, int32_t res_tiled, const float* dev_gamma,
