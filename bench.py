@@ -28,6 +28,7 @@ from clip_amd.config import BertConfig  # noqa: E402
 from clip_amd.weights import procedural_state_dict  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0      # HBM3E, same guide
 PMC_FILE = "r02_pmc_traffic.json"
 DNOTE_THRESHS = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
 
@@ -43,6 +44,43 @@ def flops_saved_per_row(L, cfg):
     are computed there; K and V still need every token."""
     H, I = cfg.hidden_size, cfg.intermediate_size
     return 2 * (L - 1) * (2 * H * H + 2 * H * I) + 4 * L * H * (L - 1)
+
+
+def roofline_by_kernel(kernel_ms, lens, cfg, precision, steps):
+    """Every kernel kind of one step against ITS bound (north_star: MFMA fraction for the encoder GEMMs, HBM GB/s
+    for the memory-bound kernels): algorithmic FLOPs and bytes per step (DESIGN.md §4's table: operands read
+    once, outputs written once, real tokens only), the HIP-event time of the kind per step, and the fraction of
+    whichever roofline takes longer for that work (2.5 PF dense MFMA vs 8 TB/s HBM)."""
+    H, I, NL = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    T, n = int(lens.sum()), len(lens)
+    full = NL - 1                                        # layers run on every token (the last one is trimmed)
+    ln_copies = {"bf16": 2, "f16": 1}.get(precision, 0)  # LayerNorm output copies a fused GEMM writes (16-bit each)
+    unfused = ln_copies == 0                             # f16r: fp32 pre-LayerNorm rows out, fp32 rows + stats in
+    ln_io = (T * H * 2 * (1 + ln_copies)) if not unfused else (T * H * 4 * 2)
+    work = {
+        "embed_ln": (0.0, T * H * 4 + T * H * 2 * max(ln_copies, 1)),
+        "gemm_qkv": (full * 2.0 * T * H * 3 * H + 2.0 * T * H * 2 * H,
+                     full * (T * H * 2 + 3 * H * H * 2 + T * 3 * H * 2) + (T * H * 2 + 2 * H * H * 2 + T * 2 * H * 2)),
+        "attention": (full * float(sum(4.0 * int(L) * int(L) * H for L in lens)), full * (T * 3 * H * 2 + T * H * 2)),
+        "gemm_attn_out": (full * 2.0 * T * H * H, full * (T * H * 2 + H * H * 2 + ln_io)),
+        "gemm_ffn_up": (full * 2.0 * T * H * I, full * (T * H * 2 + I * H * 2 + T * I * 2)),
+        "gemm_ffn_down": (full * 2.0 * T * I * H, full * (T * I * 2 + I * H * 2 + ln_io)),
+        "layernorm": (0.0, 2 * full * (T * H * 4 + T * H * 2) if unfused else 0),
+        "last_layer_rows": (2.0 * n * (2 * H * H + 2 * H * I) + float(sum(4.0 * int(L) * H for L in lens)),
+                            T * 2 * H * 2 + (2 * H * H + 2 * H * I) * 2),
+        "head": (2.0 * n * H * cfg.num_labels, n * H * 2 + n * cfg.num_labels * 4),
+    }
+    out = {}
+    for kind, (flops, nbytes) in work.items():
+        ms = kernel_ms.get(kind, 0.0)
+        if ms <= 0:
+            continue
+        tf, gbps = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+        bound = "mfma" if flops / (PEAK_BF16_TFLOPS * 1e12) > nbytes / (PEAK_HBM_GBPS * 1e9) else "hbm"
+        out[kind] = {"ms_per_step": round(ms, 4), "gflop_per_step": round(flops / 1e9, 2), "mb_per_step": round(nbytes / 1e6, 1),
+                     "tflops": round(tf, 1), "gbps": round(gbps, 1), "bound": bound,
+                     "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else gbps / PEAK_HBM_GBPS, 4)}
+    return out
 
 
 def make_batch(rows, device):
@@ -67,7 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows-per-step", type=int, default=510)
     ap.add_argument("--seq-len", type=int, default=256)
-    ap.add_argument("--precision", choices=["bf16", "f16"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "f16", "f16r"], default="bf16",
                     help="operand type of the kernels (clip_set_precision); the headline metric is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every kernel kind (extra events)")
@@ -150,7 +188,7 @@ def main():
     # timed steps: the nameplate 2.5 PF assumes 2.4 GHz, which no board holds under a dense MFMA stream
     peak_best, peak_mean, peak_ms = C.c_double(0), C.c_double(0), C.c_double(0)
     if rank == 0:
-        _lib.check(lib.clip_mfma_peak(_lib.PRECISION_F16 if args.precision == "f16" else _lib.PRECISION_BF16, 12000, 5, C.byref(peak_best), C.byref(peak_mean),
+        _lib.check(lib.clip_mfma_peak(_lib.PRECISION_F16 if args.precision.startswith("f16") else _lib.PRECISION_BF16, 12000, 5, C.byref(peak_best), C.byref(peak_mean),
                                       C.byref(peak_ms)))
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
@@ -253,6 +291,22 @@ def main():
             raise RuntimeError("global top-k over %d rank(s) differs from one sort over all records" % world)
         if args.breakdown:
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
+            res["roofline_by_kernel"] = roofline_by_kernel({k: ms[i] / args.steps for i, k in enumerate(_lib.KINDS)},
+                                                           batches[0]["lens"], cfg, args.precision, args.steps)
+        if world == 1:
+            # what precision='auto' (the default everywhere but here: the headline metric is bf16) selects for these
+            # weights, with the numbers it measured (clip_amd/precision.py), outside the timed region
+            probe = BertSequenceMultilabelClassificationContext(cfg, max_tokens=32768, max_seqs=1024)
+            probe._sd = model._sd
+            probe.to(device)
+            probe.set_sep_token_id(102); probe.set_n_context_sentences(n_ctx)
+            probe.calibrate_precision(all_rows[:512], log=False)
+            rep = probe.precision_report
+            res["precision_auto"] = {"selected": rep["selected"], "meets_criteria": rep["meets_criteria"],
+                                     "sample_rows": rep["sample_rows"],
+                                     "candidates": {k: {kk: vv for kk, vv in v.items() if kk != "rms_logit_err"}
+                                                    for k, v in rep["candidates"].items()}}
+            probe._drop_engine()
         if world == 1 and not args.no_cpu_baseline:
             from oracle import bert_oracle as O    # CPU baseline leg only
             sample = all_rows[:args.rows_per_step]

@@ -9,7 +9,8 @@ LIB_PATH = os.environ.get("CLIP_AMD_LIB") or os.path.join(_HERE, "lib", "libclip
 CLIP_OK, CLIP_ERR_ARG, CLIP_ERR_HIP, CLIP_ERR_STATE, CLIP_ERR_CAPACITY, CLIP_ERR_SEP_COUNT = 0, -1, -2, -3, -4, -5
 KINDS = ("embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn_up",
          "gemm_ffn_down", "head", "last_layer_rows")
-PRECISION_BF16, PRECISION_FP32, PRECISION_F16 = 0, 1, 2
+PRECISION_BF16, PRECISION_FP32, PRECISION_F16, PRECISION_F16R = 0, 1, 2, 3
+PRECISIONS = {"bf16": PRECISION_BF16, "fp32": PRECISION_FP32, "f16": PRECISION_F16, "f16r": PRECISION_F16R}
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_TANH = 0, 1, 2, 3
 
 
@@ -87,7 +88,7 @@ def load():
     return lib
 
 
-ERR_LN_TIMEOUT, ERR_ROW_TABLE = 2, 4     # bits of the device error word (clip_poll_errors)
+ERR_LN_TIMEOUT, ERR_ROW_TABLE, ERR_NONFINITE = 2, 4, 8     # bits of the device error word (clip_poll_errors)
 
 
 def poll_errors(engine):
@@ -100,6 +101,10 @@ def poll_errors(engine):
     if flags.value & ERR_ROW_TABLE:
         raise ValueError(f"engine error word {flags.value}: inconsistent row table (a row longer than max_seqlen, "
                          "an empty row, or cu_seqlens not ending at total_tokens); results of the call are void")
+    if flags.value & ERR_NONFINITE:
+        raise FloatingPointError(f"engine error word {flags.value}: non-finite logits (an activation left the operand "
+                                 "type's range — fp16 tops out at 65504: use precision 'bf16' or 'fp32' for this "
+                                 "checkpoint — or a weight is NaN); results of the call are void")
     if flags.value:
         raise RuntimeError(f"engine error word {flags.value}")
 

@@ -14,10 +14,12 @@ With --topk K it also writes `ttp_top{K}.csv` WITH the header `doc_id,sent_ix,ma
 file sentclf/pretrain_tasks.py:37,57-58 reads as `focus_fname` (README.md:43: "sorted by decreasing
 max_label_score ... take the top 250k").
 
-One process per GPU: under `torch.distributed.run` the rows are cut into chunks of whole documents,
-chunk c belongs to rank c mod world, every rank scores its chunks with no communication and keeps a
-running top-k; CSV parts are concatenated in chunk order (= input order) and the top-k uses one
-all-gather.
+One process per GPU (`--gpus N`, or under `torch.distributed.run`): EVERY rank reads the CSV's document index,
+takes a contiguous range of whole documents balanced by tokens (exact counts for a columnar directory; for CSV
+text the cells' byte lengths over each row's context window stand in for them), and runs the same pipeline
+on its own range — tokenise a piece on a helper thread while the GPU scores the piece before — so no rank
+waits for another before its first step and none tokenises for another.  CSV parts are concatenated in
+(rank, piece) order = input order and the top-k uses one all-gather.
 """
 import argparse
 import os
@@ -35,9 +37,27 @@ from .fast_tokenizer import FastWordPiece, build_rows_chunks, build_rows_fast
 from .config import BertConfig
 from .constants import LABEL_TYPES
 from .datasets import SentDataset, SentEvalDataset
-from .columnar import ColumnarCorpus, graded_chunk_bounds, save_rows
+from .columnar import ColumnarCorpus, chunk_bounds, graded_chunk_bounds, merge_parts, save_rows
 from .job import RunningTopK, write_topk_csv
 from .scoring import BulkScorer, PackedRows, write_ttp_csv
+
+
+def token_proxy(dataset, n):
+    """A weight per row that follows its token count without tokenising: the bytes of the sentence cells of the
+    row's context window — the +-n rows that belong to the same document (neural_baselines.py:219-235), a
+    constant for a <DOC_START> / <DOC_END> stand-in — plus a constant for [CLS] and the [SEP]s."""
+    N = len(dataset)
+    cell = dataset.sents["sentence"].str.len().to_numpy(dtype=np.int64, na_value=0)
+    doc = np.asarray(dataset.doc_ids)
+    i = np.arange(N)
+    w = cell + 8 * (2 * n + 2)
+    for o in range(-n, n + 1):
+        if o == 0:
+            continue
+        j = np.clip(i + o, 0, N - 1)
+        same = (i + o >= 0) & (i + o < N) & (doc[j] == doc)
+        w = w + np.where(same, cell[j], 40)
+    return w
 
 
 def main(argv=None):
@@ -57,8 +77,10 @@ def main(argv=None):
                         help="rows scored per chunk of whole documents (bounds host memory; chunk c -> rank c mod world)")
     parser.add_argument("--save_rows", type=str, default=None,
                         help="write the tokenised rows as a columnar directory (tokenise once, score many times)")
-    parser.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
-                        help="operand type of the GEMM / attention kernels (clip_set_precision)")
+    parser.add_argument("--precision", choices=["auto", "bf16", "f16", "f16r", "fp32"], default="auto",
+                        help="numerics setting of the kernels (clip_set_precision); auto = the fastest 16-bit setting that "
+                             "measures inside 2e-2 on the logits and 99.9 %% label agreement against the fp32 check mode on a "
+                             "sample of this input (clip_amd/precision.py)")
     parser.add_argument("--gpus", type=int, default=1,
                         help="ranks to start, one per MI355X (documents are sharded; ignored under torchrun)")
     parser.add_argument("--tokenize_only", action="store_true", help="stop after --save_rows (needs no GPU)")
@@ -70,7 +92,8 @@ def main(argv=None):
 
     def stamp(what):
         if timing:
-            print(f"[clip_amd timing] {time.perf_counter() - t_start:7.3f} s  {what}", file=sys.stderr, flush=True)
+            print(f"[clip_amd timing] rank {os.environ.get('RANK', '0')} {time.perf_counter() - t_start:7.3f} s  {what}",
+                  file=sys.stderr, flush=True)
 
     if args.task != "multilabel":
         raise NotImplementedError("only --task multilabel is on the accelerated path")
@@ -101,78 +124,92 @@ def main(argv=None):
         model.set_precision(args.precision)
         model.to(device).eval()                                                            # :72,100
         stamp("state dict loaded")
-        with torch.cuda.device(device):
-            model._ensure_engine()
-        stamp("engine ready")
+        if args.precision != "auto":      # (auto: the engine is built after the calibration on this input's rows)
+            with torch.cuda.device(device):
+                model._ensure_engine()
+            stamp("engine ready")
         return model
 
     pool = ThreadPoolExecutor(max_workers=3)
     build = pool.submit(build_model) if not args.tokenize_only else None
 
-    # ---- rows: a columnar directory as it is, or the CSV through the C++ front end — ONCE per job:
-    # rank 0 tokenises on all host cores and writes the columnar directory, every rank memory-maps it
-    # (N ranks tokenising the same CSV would be N x the work on the same cores)
+    # ---- rows.  A columnar directory as it is; a CSV through the C++ front end.  Every rank reads the document
+    # index (doc_id per row) and cuts the SAME rank ranges from it — contiguous, whole documents, balanced by
+    # tokens — so each rank knows its own range and every other rank's piece count without a message.
     out_dir = os.path.dirname(args.local_weights) or "."                               # :90
-    stream = None            # single rank, CSV input: (dataset, tokenizer, bounds) of the pipelined tokenizer
+    n = args.n_context_sentences
+    corpus = dataset = tokenizer = meta = None
     if os.path.isdir(args.unlabeled_fname):
-        corpus_dir = args.unlabeled_fname
-        corpus = None
+        corpus = ColumnarCorpus(args.unlabeled_fname)
+        if corpus.meta.get("n_context_sentences") != n:
+            raise ValueError(f"{args.unlabeled_fname} was tokenised with n_context_sentences="
+                             f"{corpus.meta.get('n_context_sentences')}, not {n}")
+        doc_index, weights = corpus.doc_ids, np.diff(corpus.offsets)                       # exact token counts
+        sep_id = int(corpus.meta["sep_token_id"])
+        piece_rows = args.chunk_rows
+        cut = chunk_bounds
     else:
-        corpus_dir = args.save_rows or (os.path.join(out_dir, "ttp_rows.columnar") if world > 1 else None)
-        corpus = None
-        if rank == 0:
-            # C++ WordPiece (libclip_tok.so); the Python restatement behind it takes what it flags
-            tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                # :43-47
-            if args.n_context_sentences == 0:                                              # :83-88
-                dataset = SentDataset(args.unlabeled_fname, args.task)
-            else:
-                dataset = SentEvalDataset(args.unlabeled_fname, args.task,
-                                          n_context_sentences=args.n_context_sentences)
-            stamp(f"CSV read ({len(dataset)} rows)")
-            meta = dict(n_context_sentences=args.n_context_sentences, sep_token_id=tokenizer.sep_token_id,
-                        cls_token_id=tokenizer.cls_token_id, vocab_size=len(tokenizer.vocab),
-                        source=os.path.basename(args.unlabeled_fname))
-            if world == 1 and not args.tokenize_only:
-                # one rank: tokenise in pieces of whole documents on a helper thread WHILE the GPU scores the
-                # piece before (any chunking gives the same files: parts are concatenated in order and the
-                # top-k is a running merge); the first pieces are small so that the GPU starts early
-                stream = (dataset, tokenizer, graded_chunk_bounds(dataset.doc_ids, min(args.chunk_rows, 131_072)), meta)
-            else:
-                rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, args.n_context_sentences)
-                if corpus_dir:
-                    save_rows(corpus_dir, rows, doc_ids, sent_ixs, **meta)
-                if world == 1:
-                    corpus = ColumnarCorpus.from_arrays(rows, doc_ids, sent_ixs, **meta)
-        if dist is not None:
-            dist.barrier()
-    if corpus is None and stream is None:
-        corpus = ColumnarCorpus(corpus_dir)
-        if corpus.meta.get("n_context_sentences") != args.n_context_sentences:
-            raise ValueError(f"{corpus_dir} was tokenised with n_context_sentences="
-                             f"{corpus.meta.get('n_context_sentences')}, not {args.n_context_sentences}")
-    sep_id = int((corpus.meta if corpus is not None else stream[3])["sep_token_id"])
+        # C++ WordPiece (libclip_tok.so); the Python restatement behind it takes what it flags
+        tokenizer = FastWordPiece(os.path.join(args.model, "vocab.txt"))                    # :43-47
+        if n == 0:                                                                         # :83-88
+            dataset = SentDataset(args.unlabeled_fname, args.task)
+        else:
+            dataset = SentEvalDataset(args.unlabeled_fname, args.task, n_context_sentences=n)
+        stamp(f"CSV read ({len(dataset)} rows)")
+        meta = dict(n_context_sentences=n, sep_token_id=tokenizer.sep_token_id, cls_token_id=tokenizer.cls_token_id,
+                    vocab_size=len(tokenizer.vocab), source=os.path.basename(args.unlabeled_fname))
+        doc_index, weights = dataset.doc_ids, token_proxy(dataset, n)
+        sep_id = int(tokenizer.sep_token_id)
+        # pieces of whole documents tokenised on a helper thread WHILE the GPU scores the piece before (any
+        # chunking gives the same files: parts are concatenated in order and the top-k is a running merge);
+        # the first pieces are small so that the GPU starts early
+        piece_rows = min(args.chunk_rows, 131_072)
+        cut = graded_chunk_bounds
+    N = len(doc_index)
+
+    def rank_bounds(r):
+        a, b = topk_mod.shard_documents(doc_index, weights, world, r)
+        return [(a + x, a + y) for x, y in cut(doc_index[a:b], piece_rows)]
+    bounds = rank_bounds(rank)
+    stamp(f"rows {bounds[0][0] if bounds else 0}..{bounds[-1][1] if bounds else 0} of {N} in {len(bounds)} pieces")
+
     if args.tokenize_only:
-        if not args.save_rows:
-            raise ValueError("--tokenize_only needs --save_rows")
-        print(f"tokenised {len(corpus)} rows / {corpus.meta['tokens']} tokens -> {args.save_rows}")
+        if not args.save_rows or corpus is not None:
+            raise ValueError("--tokenize_only needs a CSV and --save_rows")
+        rows, doc_ids, sent_ixs = build_rows_fast(dataset, tokenizer, n)
+        save_rows(args.save_rows, rows, doc_ids, sent_ixs, **meta)
+        print(f"tokenised {len(rows)} rows / {int(rows.offsets[-1])} tokens -> {args.save_rows}")
         return None
+
+    def rows_of(block_bounds):
+        """(PackedRows, doc_ids, sent_ixs) for each (a, b) row range, from either kind of input"""
+        if corpus is not None:
+            return (corpus.slice(a, b) for a, b in block_bounds)
+        return build_rows_chunks(dataset, tokenizer, n, block_bounds)
 
     model = build.result()
     if args.n_context_sentences > 0:
         model.set_sep_token_id(sep_id)                                                 # :74
         model.set_n_context_sentences(args.n_context_sentences)                        # :75
     model.set_task(args.task)                                                          # :80
+    if args.precision == "auto" and N:
+        # measured on 8 runs of 64 rows spread over the WHOLE input — the same sample on every rank, so every
+        # rank reaches the same setting without a message
+        per = min(64, max(N // 8, 1))
+        starts = sorted({int(x) for x in (np.arange(8) * (N - per) // 7)})
+        blocks = [r for r, _, _ in rows_of([(a, min(a + per, N)) for a in starts])]
+        lens = np.concatenate([r.lens for r in blocks]).astype(np.int64)
+        sample = PackedRows(np.concatenate([r.flat for r in blocks]), np.concatenate(([0], np.cumsum(lens))))
+        model.calibrate_precision(sample, log=sys.stderr if rank == 0 else False)
+        stamp(f"precision auto -> {model.resolved_precision}")
 
-    # ---- the hot loop (:92-124), chunk by chunk: score, append this chunk's CSV part, fold into the
-    # running top-k.  Chunks are whole documents; chunk c belongs to rank c mod world.
+    # ---- the hot loop (:92-124), piece by piece over this rank's range: score, write the piece's CSV part,
+    # fold into the running top-k.  Pieces are whole documents.
     scorer = BulkScorer(model, any_threshold=args.threshold)
     out = os.path.join(out_dir, "ttp_doc_sents.csv")
+    kept = []                # --save_rows: this rank's pieces
+
     def chunk_source():
-        if stream is None:
-            for c, a, b, item in corpus.chunks(args.chunk_rows, rank, world):
-                yield (c,) + item
-            return
-        dataset, tokenizer, bounds, meta = stream
         q = queue.Queue(maxsize=2)
         stop = threading.Event()        # the consumer gave up (an exception in scoring): the producer must not block forever
 
@@ -187,7 +224,7 @@ def main(argv=None):
 
         def produce():
             try:
-                for c, item in enumerate(build_rows_chunks(dataset, tokenizer, args.n_context_sentences, bounds)):
+                for c, item in enumerate(rows_of(bounds)):
                     if not put((c,) + item):
                         return
                 put(None)
@@ -195,7 +232,6 @@ def main(argv=None):
                 put(exc)
 
         pool.submit(produce)
-        kept = []
         try:
             while True:
                 item = q.get()
@@ -203,20 +239,14 @@ def main(argv=None):
                     break
                 if isinstance(item, BaseException):
                     raise item
-                if args.save_rows:
+                if args.save_rows and corpus is None:
                     kept.append(item[1:])
                 yield item
         finally:
             stop.set()
-        if args.save_rows:
-            lens = np.concatenate([k[0].lens for k in kept]) if kept else np.zeros(0, np.int64)
-            rows = PackedRows(np.concatenate([k[0].flat for k in kept]) if kept else np.zeros(0, np.int32),
-                              np.concatenate(([0], np.cumsum(lens, dtype=np.int64))))
-            save_rows(args.save_rows, rows, np.concatenate([k[1] for k in kept]), np.concatenate([k[2] for k in kept]), **meta)
 
-    n_chunks = len(stream[2]) if stream is not None else len(corpus.chunk_bounds(args.chunk_rows))
     top = RunningTopK(args.topk) if args.topk > 0 else None
-    counts = [0, 0]          # rows, kept
+    counts = [0, 0, 0]       # rows, kept, tokens
     res = None
     writes = []
     post = ThreadPoolExecutor(max_workers=1)       # per-chunk host work, in chunk order, off the scoring thread
@@ -227,38 +257,54 @@ def main(argv=None):
         counts[0] += len(r.keep)
         counts[1] += int(r.keep.sum())
 
+    part = lambda r, c: f"{out}.r{r:04d}.chunk{c:06d}"
     for c, rows_c, d_c, s_c in chunk_source():
-        stamp(f"chunk {c} tokenised ({len(d_c)} rows)")
+        stamp(f"piece {c} ready ({len(d_c)} rows)")
         res = scorer.score(rows_c, d_c, s_c)
-        stamp(f"chunk {c} scored")
-        # formatted / folded into the running top-k while the next chunk is scored
-        writes.append(pool.submit(write_ttp_csv, f"{out}.chunk{c}", res))
+        counts[2] += int(rows_c.offsets[-1])
+        stamp(f"piece {c} scored")
+        # formatted / folded into the running top-k while the next piece is scored
+        writes.append(pool.submit(write_ttp_csv, part(rank, c), res))
         writes.append(post.submit(fold, res))
     for w in writes:
         w.result()
     pool.shutdown()
     post.shutdown()
-    n_rows, n_kept = counts
-    stamp("CSV parts written")
+    n_rows, n_kept, n_tokens = counts
+    stamp(f"CSV parts written ({n_rows} rows, {n_tokens} tokens on this rank)")
+    if args.save_rows and corpus is None:               # this rank's rows; rank 0 joins the parts below
+        lens = np.concatenate([k[0].lens for k in kept]).astype(np.int64) if kept else np.zeros(0, np.int64)
+        mine = PackedRows(np.concatenate([k[0].flat for k in kept]) if kept else np.zeros(0, np.int32),
+                          np.concatenate(([0], np.cumsum(lens))))
+        save_rows(args.save_rows if world == 1 else f"{args.save_rows}.part{rank:04d}", mine,
+                  np.concatenate([k[1] for k in kept]) if kept else np.zeros(0, np.int64),
+                  np.concatenate([k[2] for k in kept]) if kept else np.zeros(0, np.int64), **meta)
     if dist is not None:
         dist.barrier()
-    if rank == 0:                                       # parts in chunk order = input order (:97-98,124)
+    if rank == 0:                                       # parts in (rank, piece) order = input order (:97-98,124)
         with open(out, "wb") as f:                      # bytes: csv.writer's '\r\n' row ends stay as the reference writes them
-            for c in range(n_chunks):
-                with open(f"{out}.chunk{c}", "rb") as g:
-                    f.write(g.read())
-                os.remove(f"{out}.chunk{c}")
+            for r in range(world):
+                for c in range(len(bounds if r == rank else rank_bounds(r))):
+                    with open(part(r, c), "rb") as g:
+                        f.write(g.read())
+                    os.remove(part(r, c))
+        if args.save_rows and corpus is None and world > 1:
+            merge_parts([f"{args.save_rows}.part{r:04d}" for r in range(world)], args.save_rows, **meta)
     if top is not None:
         glob = topk_mod.global_topk(top.records, args.topk)
         if rank == 0:
             write_topk_csv(os.path.join(out_dir, f"ttp_top{args.topk}.csv"), glob)
-    tot = torch.tensor([n_kept, n_rows], dtype=torch.int64,
+    tot = torch.tensor([n_kept, n_rows, n_tokens], dtype=torch.int64,
                        device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tot)                            # counts over all ranks
     stamp("files complete")
+    if timing:
+        print(f"[clip_amd timing] rank {rank}: {n_tokens} tokens = {100.0 * n_tokens * world / max(int(tot[2]), 1):.2f} % "
+              "of an even share", file=sys.stderr, flush=True)
     if rank == 0:
-        print(f"done! results in {out_dir}  ({int(tot[0])} of {int(tot[1])} sentences selected, {world} rank(s))")
+        print(f"done! results in {out_dir}  ({int(tot[0])} of {int(tot[1])} sentences selected, {world} rank(s), "
+              f"precision {model.resolved_precision})")
     if dist is not None:
         dist.destroy_process_group()
     return res

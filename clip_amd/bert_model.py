@@ -62,19 +62,41 @@ class _EngineModel:
         self.device = torch.device("cpu")
         self._sd = None
         self._engine = None
-        self.precision = "bf16"
+        self.precision = "auto"             # what the caller asked for
+        self.resolved_precision = None      # what the engine runs in ('auto' resolved by calibrate_precision)
+        self.precision_report = None
 
     def set_precision(self, precision):
-        """'bf16' (default; logits within 2e-2 of the fp32 reference on benign weights), 'f16' (fp16
-        operands at the same speed: 1/8 of bf16's operand rounding — within 2e-2 also on trained-like
-        weights with logits beyond +-6 — at the price of fp16's range) or 'fp32' (check mode: the same
-        kernels on fp32 operands, within 1e-4; ~16x slower).  Rebuilds the engine on next use."""
-        if precision not in ("bf16", "f16", "fp32"):
-            raise ValueError(f"precision must be 'bf16', 'f16' or 'fp32', not {precision!r}")
+        """'auto' (default): the fastest 16-bit setting that MEASURES inside the parity criteria of BASELINE.json
+        on a sample — logits within 2e-2 of the fp32 check mode and >= 99.9 % thresholded-label agreement
+        (clip_amd/precision.py; the choice is printed and kept in .precision_report).  Or fixed: 'bf16' (bf16
+        operands; within 2e-2 on benign weights, logits of +-2), 'f16' (fp16 operands at the same speed, 1/8 of
+        bf16's operand rounding, at the price of fp16's range), 'f16r' (fp16 operands + fp32 residual stream:
+        inside 2e-2 on the trained-like stress goldens, ~17 % slower) or 'fp32' (check mode: the same kernels on
+        fp32 operands, within 1e-4; ~16x slower).  Rebuilds the engine on next use."""
+        if precision not in ("auto",) + tuple(_lib.PRECISIONS):
+            raise ValueError(f"precision must be 'auto', 'bf16', 'f16', 'f16r' or 'fp32', not {precision!r}")
         if precision != self.precision:
             self._drop_engine()
             self.precision = precision
+            self.resolved_precision = None if precision == "auto" else precision
+            self.precision_report = None
         return self
+
+    def calibrate_precision(self, rows=None, label_threshs=None, log=None):
+        """Resolve precision='auto' now, on `rows` (token-id rows of the caller's own input; default: synthetic rows
+        of this model's layout).  No-op for a fixed precision or an already resolved model.  Returns the setting."""
+        if self.precision == "auto" and self.resolved_precision is None:
+            from . import precision as P
+            if self.device.type != "cuda":
+                raise RuntimeError("the model must be moved to an MI355X first (model.to('cuda')); "
+                                   "clip_amd has no CPU execution path")
+            if self._sd is None:
+                raise RuntimeError("no weights loaded (from_pretrained / load_state_dict)")
+            self.precision_report = P.choose_precision(self, rows, label_threshs, log)
+            self._drop_engine()
+            self.resolved_precision = self.precision_report["selected"]
+        return self.resolved_precision
 
     # ---- construction (test_load.py:21, apply_bert_unlabeled.py:65-70,78-79)
     @classmethod
@@ -116,6 +138,8 @@ class _EngineModel:
                 raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(shapes[k])}")
         self._sd = {k: sd[k].detach().to("cpu", torch.float32).contiguous() for k in shapes if k in sd}
         self._drop_engine()
+        if self.precision == "auto":        # new weights: measure again
+            self.resolved_precision = self.precision_report = None
         return missing, unexpected
 
     def state_dict(self):
@@ -169,6 +193,7 @@ class _EngineModel:
         if self._sd is None:
             raise RuntimeError("no weights loaded (from_pretrained / load_state_dict)")
         lib = _lib.load()
+        self.calibrate_precision()          # precision='auto' not yet resolved: synthetic sample
         c = self.config
         cc = _lib.ClipConfig(c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads,
                              c.intermediate_size, c.max_position_embeddings, c.type_vocab_size,
@@ -176,8 +201,7 @@ class _EngineModel:
         h = C.c_void_p()
         _lib.check(lib.clip_create(C.byref(cc), self.device.index, C.byref(h)))
         try:
-            _lib.check(lib.clip_set_precision(h, {"bf16": _lib.PRECISION_BF16, "fp32": _lib.PRECISION_FP32,
-                                                  "f16": _lib.PRECISION_F16}[self.precision]))
+            _lib.check(lib.clip_set_precision(h, _lib.PRECISIONS[self.resolved_precision]))
             for k, v in self._sd.items():
                 _lib.check(lib.clip_load_weight(h, k.encode(), C.c_void_p(v.data_ptr()), v.numel()))
             _lib.check(lib.clip_finalize_weights(h))

@@ -40,6 +40,36 @@ def save_rows(path, rows: PackedRows, doc_ids, sent_ixs, **meta):
         json.dump(meta, f, indent=1)
 
 
+def merge_parts(part_dirs, path, **meta):
+    """Join columnar directories that hold consecutive row ranges of one corpus (the ranks' --save_rows parts,
+    in rank order) into `path`, streaming through memory maps, and remove the parts."""
+    import shutil
+    parts = [ColumnarCorpus(d) for d in part_dirs]
+    n_rows = sum(len(p) for p in parts)
+    n_tok = sum(int(p.offsets[-1]) for p in parts)
+    os.makedirs(path, exist_ok=True)
+    open_out = lambda name, dtype, n: np.lib.format.open_memmap(os.path.join(path, name + ".npy"), mode="w+",
+                                                                dtype=dtype, shape=(n,))
+    flat, offsets = open_out("flat", np.int32, n_tok), open_out("offsets", np.int64, n_rows + 1)
+    doc_ids, sent_ixs = open_out("doc_ids", np.int64, n_rows), open_out("sent_ixs", np.int64, n_rows)
+    r = t = 0
+    offsets[0] = 0
+    for p in parts:
+        k, m = len(p), int(p.offsets[-1])
+        flat[t:t + m] = p.flat
+        offsets[r + 1:r + k + 1] = np.asarray(p.offsets[1:]) + t
+        doc_ids[r:r + k], sent_ixs[r:r + k] = p.doc_ids, p.sent_ixs
+        r, t = r + k, t + m
+    for a in (flat, offsets, doc_ids, sent_ixs):
+        a.flush()
+    del flat, offsets, doc_ids, sent_ixs, parts
+    meta = dict(meta, rows=int(n_rows), tokens=int(n_tok), format="clip_amd.columnar/1")
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    for d in part_dirs:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def chunk_bounds(doc_ids, chunk_rows):
     """Row ranges of about chunk_rows rows that end on document boundaries (rows of a document are
     contiguous, as in the reference's CSVs).  A document longer than chunk_rows is one chunk."""

@@ -69,7 +69,8 @@ struct clip_engine {
   // numerics setting of the SAME kernels (clip_set_precision): false = bf16 operands / fp32
   // accumulation, true = fp32 check mode (fp32 weights, activations and MFMA)
   bool f32 = false;
-  bool f16 = false;  // CLIP_PRECISION_F16: the k_f16 kernel set (fp16 operands, same MFMA rate, 11-bit significand)
+  bool f16 = false;  // CLIP_PRECISION_F16 / F16R: the k_f16 kernel set (fp16 operands, same MFMA rate, 11-bit significand)
+  bool res32 = false;  // CLIP_PRECISION_F16R: fp32 residual stream (fp32 pre-LayerNorm rows + (mean, rstd); no LayerNorm fusion)
   // workspace (allocated by clip_finalize_weights, element size by precision)
   void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *rows = nullptr,
        *pooled = nullptr, *ctx_rows = nullptr, *mid_rows = nullptr, *xf_rows = nullptr, *q_rows = nullptr;
@@ -320,7 +321,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
   // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
   // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
-  const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
+  const bool fused = !f32 && !e->res32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
   int cur = 0;
   const float *g_prev = e->embg, *b_prev = e->embb;
   // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
@@ -610,12 +611,14 @@ int clip_destroy(clip_engine* e) {
 
 int clip_set_precision(clip_engine* e, int32_t precision) {
   if (!e) return fail(CLIP_ERR_ARG, "clip_set_precision: null engine");
-  if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32 && precision != CLIP_PRECISION_F16)
+  if (precision != CLIP_PRECISION_BF16 && precision != CLIP_PRECISION_FP32 && precision != CLIP_PRECISION_F16 &&
+      precision != CLIP_PRECISION_F16R)
     return fail(CLIP_ERR_ARG, "clip_set_precision: unknown precision %d", precision);
   if (e->finalized || e->stats_rows[1])
     return fail(CLIP_ERR_STATE, "clip_set_precision: call before clip_finalize_weights");
   e->f32 = precision == CLIP_PRECISION_FP32;
-  e->f16 = precision == CLIP_PRECISION_F16;
+  e->f16 = precision == CLIP_PRECISION_F16 || precision == CLIP_PRECISION_F16R;
+  e->res32 = precision == CLIP_PRECISION_F16R;
   return CLIP_OK;
 }
 
@@ -796,7 +799,7 @@ int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens) {
   const clip_config& c = e->cfg;
   *tokens = c.max_tokens;
   const int H = c.hidden_size;
-  if (e->f32 || !e->fuse_ln || H % 256 || H / 256 > 8 || c.intermediate_size % 128) return CLIP_OK;
+  if (e->f32 || e->res32 || !e->fuse_ln || H % 256 || H / 256 > 8 || c.intermediate_size % 128) return CLIP_OK;
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
   // the fused-LayerNorm GEMMs run (CUs / column tiles) row panels of 256 tokens side by side: whole

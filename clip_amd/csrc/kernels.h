@@ -126,7 +126,7 @@ struct k_f16 { CLIP_KERNEL_SET_MEMBERS };
 hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
                              int32_t* err, hipStream_t st);
 // logits[0..count) = NaN when *err != 0
-hipError_t launch_poison_logits(const int32_t* err, float* logits, int count, hipStream_t st);
+hipError_t launch_poison_logits(int32_t* err, float* logits, int count, hipStream_t st);
 
 // Per-device one-time launch set-up (function attributes, CU count): a process may hold engines on
 // several GPUs, and two host threads may make their first call at once.

@@ -321,10 +321,15 @@ __global__ __launch_bounds__(256) void check_rows_kernel(const int32_t* __restri
 // Last kernel of a forward: a non-zero device error word (fused-LayerNorm exchange timed out, bad row
 // table) turns every logit of the call into NaN, so that a void result cannot be mistaken for scores
 // even by a caller that never polls clip_poll_errors.
-__global__ __launch_bounds__(256) void poison_logits_kernel(const int32_t* __restrict__ err,
+// A call whose own logits are not finite (an fp16 activation beyond 65504 -> inf -> NaN, a NaN weight) sets
+// bit 3 of the word: `p > threshold` is False for NaN, so such a sentence would otherwise just be MISSING from
+// ttp_doc_sents.csv and the top-k file, with exit status 0.
+__global__ __launch_bounds__(256) void poison_logits_kernel(int32_t* __restrict__ err,
                                                             float* __restrict__ logits, int count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < count && *err != 0) logits[i] = __builtin_nanf("");
+  if (i >= count) return;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) logits[i] = __builtin_nanf("");
+  else if (!__builtin_isfinite(logits[i])) atomicOr(err, 8);
 }
 
 // CrossEntropyLoss rows (ref: sentclf/bert_model.py:177-182, torch CrossEntropyLoss = log_softmax + NLL):
@@ -501,7 +506,7 @@ hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_to
   return hipGetLastError();
 }
 
-hipError_t launch_poison_logits(const int32_t* err, float* logits, int count, hipStream_t st) {
+hipError_t launch_poison_logits(int32_t* err, float* logits, int count, hipStream_t st) {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(poison_logits_kernel, dim3((count + 255) / 256), dim3(256), 0, st, err, logits, count);
   return hipGetLastError();

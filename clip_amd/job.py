@@ -12,6 +12,13 @@ RUNNING top-k (k records, 16 B each: memory does not grow with the corpus), and 
 the one all-gather + deterministic merge of clip_amd.topk.  Chunk contents depend on (seed, chunk
 index) only, so the global top-k is the same for every world size — the property
 tests/test_gpu_job.py checks.
+
+Checkpoint / resume (the reference has none: apply_bert_unlabeled.py:97 reopens its output with 'w' and
+starts over): `--state FILE` keeps (next chunk, running top-k, counters, seconds so far) in one .npz per
+rank, rewritten after every chunk; `--max-seconds S` ends an invocation cleanly after the chunk that crosses
+S.  The next invocation with the same arguments continues from the file; the JSON line of the invocation
+that finishes the job reports the totals over all of them ("invocations", "seconds" = scoring time summed).
+A job split this way selects the same top-k, bit for bit, as one uninterrupted run (tests/test_gpu_job.py).
 """
 import argparse
 import json
@@ -56,37 +63,81 @@ class RunningTopK:
         return self
 
 
-def run_rank(scorer, config, n_rows, chunk_rows_n, k, rank, world, vocab_size, on_chunk=None):
-    """Score this rank's chunks; returns (RunningTopK, rows, tokens, kept)."""
+class JobState:
+    """What outlives a chunk on one rank: position in the rank's chunk list, the running top-k, counters and the
+    scoring seconds of earlier invocations.  One .npz, replaced atomically after every chunk."""
+
+    def __init__(self, k, signature):
+        self.next_i, self.top = 0, RunningTopK(k)
+        self.rows = self.tokens = self.kept = 0
+        self.seconds, self.invocations = 0.0, 1
+        self.signature = signature
+
+    @classmethod
+    def load_or_new(cls, path, k, signature):
+        st = cls(k, signature)
+        if path and os.path.isfile(path):
+            z = np.load(path, allow_pickle=False)
+            if str(z["signature"]) != signature:
+                raise ValueError(f"{path} belongs to another job ({z['signature']}), not {signature}")
+            st.next_i, st.rows, st.tokens, st.kept = (int(z[k_]) for k_ in ("next_i", "rows", "tokens", "kept"))
+            st.seconds, st.invocations = float(z["seconds"]), int(z["invocations"]) + 1
+            st.top.records = z["records"].view(topk.RECORD).reshape(-1).copy()
+        return st
+
+    def save(self, path, seconds_now):
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, signature=np.array(self.signature), next_i=self.next_i, rows=self.rows, tokens=self.tokens,
+                 kept=self.kept, seconds=self.seconds + seconds_now, invocations=self.invocations,
+                 records=self.top.records.view(np.uint8))
+        os.replace(tmp, path)
+
+
+def run_rank(scorer, config, n_rows, chunk_rows_n, k, rank, world, vocab_size, on_chunk=None, state=None,
+             state_path=None, max_seconds=None):
+    """Score this rank's chunks (from state.next_i on); returns (JobState, finished).  With state_path the state
+    file is rewritten after every chunk; with max_seconds the loop ends after the chunk that crosses it."""
     from concurrent.futures import ThreadPoolExecutor
     n_chunks = (n_rows + chunk_rows_n - 1) // chunk_rows_n
-    top = RunningTopK(k)
-    rows_done = tokens = kept = 0
+    st = state or JobState(k, "")
+    top = st.top
     mine = list(range(rank, n_chunks, world))
     size = lambda c: min(chunk_rows_n, n_rows - c * chunk_rows_n)
     pool = ThreadPoolExecutor(max_workers=1)      # the next chunk's rows are made while this one is scored
     post = ThreadPoolExecutor(max_workers=1)      # ... and the previous chunk's records are folded into the top-k
-    nxt = pool.submit(chunk_rows, config, mine[0], size(mine[0]), vocab_size) if mine else None
+    i0 = st.next_i
+    nxt = pool.submit(chunk_rows, config, mine[i0], size(mine[i0]), vocab_size) if i0 < len(mine) else None
     fold = None
-    for i, c in enumerate(mine):
+    t0 = time.perf_counter()
+    finished = True
+    for i in range(i0, len(mine)):
+        c = mine[i]
         n = size(c)
         rows, doc_ids, sent_ixs = nxt.result()
+        stop = max_seconds is not None and time.perf_counter() - t0 > max_seconds and i > i0
+        if stop:
+            finished = False
+            break
         if i + 1 < len(mine):
             nxt = pool.submit(chunk_rows, config, mine[i + 1], size(mine[i + 1]), vocab_size)
         res = scorer.score(rows, doc_ids, sent_ixs)
         if fold is not None:
             fold.result()
         fold = post.submit(top.update, res.doc_ids, res.sent_ixs, res.max_score, res.keep)   # under the next chunk
-        rows_done += n
-        tokens += int(rows.lens.sum())
-        kept += int(res.keep.sum())
+        st.rows += n
+        st.tokens += int(rows.lens.sum())
+        st.kept += int(res.keep.sum())
+        st.next_i = i + 1
+        if state_path:
+            fold.result()                          # the file must hold the top-k INCLUDING this chunk
+            st.save(state_path, time.perf_counter() - t0)
         if on_chunk is not None:
             on_chunk(c, n, res)
     if fold is not None:
         fold.result()
     pool.shutdown(wait=False)
     post.shutdown(wait=False)
-    return top, rows_done, tokens, kept
+    return st, finished
 
 
 def write_topk_csv(path, records):
@@ -110,8 +161,12 @@ def main(argv=None):
     ap.add_argument("--threshold", type=float, default=0.05)
     ap.add_argument("--tokens-per-step", type=int, default=131072)
     ap.add_argument("--weights", type=str, default=None, help="state dict (.safetensors); default: procedural")
-    ap.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
-                        help="operand type of the GEMM / attention kernels (clip_set_precision)")
+    ap.add_argument("--precision", choices=["auto", "bf16", "f16", "f16r", "fp32"], default="auto",
+                    help="numerics setting (clip_set_precision); auto: measured on a sample (clip_amd/precision.py)")
+    ap.add_argument("--state", type=str, default=None,
+                    help="checkpoint file (one per rank: FILE.rankR.npz), rewritten after every chunk; an existing one is resumed")
+    ap.add_argument("--max-seconds", type=float, default=None,
+                    help="end this invocation after the chunk that crosses this many seconds of scoring (needs --state)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start, one per MI355X (ignored under torchrun)")
     ap.add_argument("--out", type=str, default=None, help="write the global top-k CSV here (rank 0)")
     ap.add_argument("--progress", action="store_true", help="one line per scored chunk on stderr")
@@ -152,24 +207,46 @@ def main(argv=None):
     def progress(c, n, res):
         print(f"[rank {rank}] chunk {c}: {n} rows, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
 
-    top, rows_done, tokens, kept = run_rank(scorer, args.config, args.rows, args.chunk_rows, args.topk, rank, world,
-                                            cfg.vocab_size, on_chunk=progress if args.progress else None)
+    if args.max_seconds is not None and not args.state:
+        raise SystemExit("--max-seconds needs --state")
+    signature = f"{args.config}/{args.rows}/{args.chunk_rows}/{args.topk}/{args.threshold}/{world}/{model.resolved_precision}"
+    state_path = f"{args.state}.rank{rank}.npz" if args.state else None
+    state = JobState.load_or_new(state_path, args.topk, signature)
+    state, finished = run_rank(scorer, args.config, args.rows, args.chunk_rows, args.topk, rank, world,
+                               cfg.vocab_size, on_chunk=progress if args.progress else None, state=state,
+                               state_path=state_path, max_seconds=args.max_seconds)
     torch.cuda.synchronize()
     t_score = time.perf_counter() - t0
+    fin = torch.tensor([int(finished)], dtype=torch.int64,
+                       device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+    if not int(fin.item()):
+        if rank == 0:
+            print(json.dumps({"job": args.config, "finished": False, "state": args.state,
+                              "rows_so_far_rank0": state.rows, "seconds_this_invocation": round(t_score, 3),
+                              "invocations": state.invocations}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return None
+    top, rows_done, tokens, kept = state.top, state.rows, state.tokens, state.kept
     glob = topk.global_topk(top.records, args.topk)
     barrier()
-    t_all = time.perf_counter() - t0
+    t_all = time.perf_counter() - t0 + state.seconds
     tot = torch.tensor([rows_done, tokens, kept], dtype=torch.int64,
                        device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tot)
     if rank == 0:
+        import resource
         if args.out:
             write_topk_csv(args.out, glob)
         print(json.dumps({
             "job": args.config, "rows": int(tot[0]), "tokens": int(tot[1]), "kept": int(tot[2]), "n_gpus": world,
             "backend": dist.get_backend() if dist is not None else None,
-            "seconds": round(t_all, 3), "rank0_scoring_seconds": round(t_score, 3),
+            "precision": model.resolved_precision, "invocations": state.invocations,
+            "peak_host_rss_mb_rank0": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1),
+            "seconds": round(t_all, 3), "rank0_scoring_seconds": round(t_score + state.seconds, 3),
             "sentences_per_s": round(int(tot[0]) / t_all, 1), "tokens_per_s": round(int(tot[1]) / t_all, 1),
             "topk": int(len(glob)), "topk_first": [int(glob[0]["doc_id"]), int(glob[0]["sent_ix"]), float(glob[0]["score"])]
             if len(glob) else None,

@@ -25,8 +25,15 @@ def _free_port():
 
 
 def visible_gpus():
-    import torch
-    return torch.cuda.device_count()      # counts devices without initialising HIP
+    """Device count for the PARENT, which must not initialise HIP (its children are started afterwards and the
+    parent only waits).  torch counts through amdsmi when it can and falls back to hipGetDeviceCount when it
+    cannot, so the count is taken in a short-lived child process and the parent stays clean either way."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
 
 
 def spawn_ranks_if_needed(n_gpus, argv=None, module=None):
@@ -53,10 +60,13 @@ def spawn_ranks_if_needed(n_gpus, argv=None, module=None):
     for r in range(n_gpus):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=env))
-    # wait for all; a rank that fails takes the others down (they would wait in a collective for it)
+    # wait for all; a rank that fails takes the others down (they would wait in a collective for it):
+    # SIGTERM first, SIGKILL for whatever is still there after the grace period (a rank stuck inside a kernel
+    # or a collective does not act on SIGTERM)
     import time
     rc = 0
     live = list(procs)
+    kill_at = None
     while live:
         for p in list(live):
             r = p.poll()
@@ -67,6 +77,11 @@ def spawn_ranks_if_needed(n_gpus, argv=None, module=None):
                 rc = r if r > 0 else 128 - r
                 for q in live:
                     q.terminate()
+                kill_at = time.monotonic() + float(os.environ.get("CLIP_AMD_KILL_GRACE_S", "30"))
+        if kill_at is not None and live and time.monotonic() > kill_at:
+            for q in live:
+                q.kill()
+            kill_at = None
         time.sleep(0.1)
     return rc
 

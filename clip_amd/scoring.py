@@ -29,6 +29,7 @@ class ScoreResult:
     keep: np.ndarray         # bool [N]     any_j(p_j > threshold)      (apply_bert_unlabeled.py:117)
     labels: np.ndarray       # bool [N, L]  p_j > label_threshs[j]      (test_load.py:38), or None
     probs: np.ndarray        # float32 [N, L] or None
+    logits: np.ndarray = None   # float32 [N, L] (keep_logits=True)
 
 
 class PackedRows:
@@ -85,22 +86,30 @@ def plan_steps(lens, tokens_per_step, max_rows_per_step):
 
 class BulkScorer:
     def __init__(self, model, any_threshold=0.05, label_threshs=None, keep_probs=False,
-                 tokens_per_step=None, max_rows_per_step=None):
+                 tokens_per_step=None, max_rows_per_step=None, keep_logits=False):
         self.model = model
         self.n_ctx = getattr(model, "n_context_sentences", None) or 0
         self.sep_id = getattr(model, "sep_token_id", None) or 0
         self.any_threshold = float(any_threshold)
         self.label_threshs = None if label_threshs is None else np.asarray(label_threshs, np.float64)
-        self.keep_probs = keep_probs
-        if tokens_per_step is None and model.device.type == "cuda":
-            t = C.c_int32(0)     # whole rounds of the fused-LayerNorm GEMMs (clip_preferred_step_tokens)
-            _lib.check(_lib.load().clip_preferred_step_tokens(model._ensure_engine(), C.byref(t)))
-            tokens_per_step = t.value
+        self.keep_probs, self.keep_logits = keep_probs, keep_logits
+        # the engine's preferred step (clip_preferred_step_tokens) is asked at the first score(): a model with
+        # precision='auto' is calibrated on that call's rows first, and only then is there an engine to ask
+        self._tokens_per_step_arg = tokens_per_step
         self.tokens_per_step = int(tokens_per_step or model.max_tokens)
         self.max_rows_per_step = int(max_rows_per_step or model.max_seqs)
         if self.tokens_per_step > model.max_tokens or self.max_rows_per_step > model.max_seqs:
             raise ValueError("step size exceeds the model's engine workspace")
         self._ws = None
+
+    def _resolve_step(self, rows):
+        model = self.model
+        # precision='auto': measured on (a spread sample of) the caller's own rows, once per model
+        model.calibrate_precision(rows, self.label_threshs)
+        if self._tokens_per_step_arg is None:
+            t = C.c_int32(0)     # whole rounds of the fused-LayerNorm GEMMs (clip_preferred_step_tokens)
+            _lib.check(_lib.load().clip_preferred_step_tokens(model._ensure_engine(), C.byref(t)))
+            self.tokens_per_step = int(t.value or model.max_tokens)
 
     def _workspace(self, dev, L):
         """Per-scorer step buffers, allocated ONCE (the step loop makes no device or pinned-host allocation; its only temporaries are the numpy index arrays of the per-step gather): device
@@ -134,12 +143,15 @@ class BulkScorer:
         sent_ixs = np.arange(N, dtype=np.int64) if sent_ixs is None else np.asarray(sent_ixs, np.int64)
         if int(rows.lens.min(initial=1)) < 1:
             raise ValueError("empty row")
+        if N:
+            self._resolve_step(rows)
         order, steps = plan_steps(rows.lens, self.tokens_per_step, self.max_rows_per_step)
 
         out_max = torch.empty(N, dtype=torch.float32, device=dev)
         out_keep = torch.empty(N, dtype=torch.uint8, device=dev)
         out_lab = torch.empty((N, L), dtype=torch.uint8, device=dev) if self.label_threshs is not None else None
         out_p = torch.empty((N, L), dtype=torch.float32, device=dev) if self.keep_probs else None
+        out_lg = torch.empty((N, L), dtype=torch.float32, device=dev) if self.keep_logits else None
         thr = None if self.label_threshs is None else torch.tensor(self.label_threshs, dtype=torch.float64, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         n_ctx_arg = self.n_ctx if self.n_ctx > 0 else -1
@@ -177,6 +189,10 @@ class BulkScorer:
                     _lib.ptr(logits), _lib.ptr(thr), self.any_threshold, n, L,
                     _lib.ptr(out_p[a:b]) if out_p is not None else None, _lib.ptr(out_max[a:b]),
                     _lib.ptr(out_lab[a:b]) if out_lab is not None else None, _lib.ptr(out_keep[a:b]), stream))
+                if out_lg is not None:
+                    out_lg[a:b].copy_(logits[:n])
+            # one 4-byte read per chunk: an exchange time-out, a bad row table, NON-FINITE logits (fp16 overflow:
+            # `p > thr` is False for NaN, the sentence would silently drop out of both output files) all raise
             _lib.poll_errors(engine)
             if int(err.item()) != 0:
                 raise TypeError(f"a row does not hold exactly {2 * self.n_ctx + 1} [SEP] tokens "
@@ -189,17 +205,11 @@ class BulkScorer:
             return res
 
         max_score = unsort(out_max)
-        bad = int(np.count_nonzero(~np.isfinite(max_score)))
-        if bad:
-            # fp16 operands overflow to inf -> NaN logits -> `p > thr` False: the sentence would silently drop out of
-            # ttp_doc_sents.csv and the top-k file.  (A device error word would have raised in poll_errors above.)
-            raise FloatingPointError(f"{bad} of {N} sentences scored non-finite in precision {model.precision!r}: "
-                                     "an activation left the operand type's range (f16: use 'bf16' or 'fp32' for "
-                                     "this checkpoint)")
         return ScoreResult(doc_ids=doc_ids, sent_ixs=sent_ixs, max_score=max_score,
                            keep=unsort(out_keep).astype(bool),
                            labels=None if out_lab is None else unsort(out_lab).astype(bool),
-                           probs=None if out_p is None else unsort(out_p))
+                           probs=None if out_p is None else unsort(out_p),
+                           logits=None if out_lg is None else unsort(out_lg))
 
 
 def write_ttp_csv(path, result: ScoreResult):

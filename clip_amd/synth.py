@@ -80,12 +80,14 @@ def documents(n_rows, seed=1004, lo=40, hi=400):
     return doc_ids, sent_ixs
 
 
-def packed_context_rows(n_rows, n_ctx=2, vocab_size=30522, max_len=256, seed=1004, sigma=0.6, seg_hi=62):
+def packed_context_rows(n_rows, n_ctx=2, vocab_size=30522, max_len=256, seed=1004, sigma=0.6, seg_hi=62,
+                        word_lo=1000, cls_id=CLS_ID, sep_id=SEP_ID):
     """Bulk form of context_rows for the full-size configs (C4: 10 M rows, C5: 50 M): the same row
     layout and segment-length law, built with array operations only, returned columnar as
     (flat int32 ids, int64 offsets) — the input of clip_amd.scoring.PackedRows.  Rows longer than
     max_len lose OUTER context tokens first (outermost pair, then the next pair, then the focus);
-    a [SEP] is never dropped.  n_ctx = 0 gives sentence-only rows ([CLS] w.. [SEP])."""
+    a [SEP] is never dropped.  n_ctx = 0 gives sentence-only rows ([CLS] w.. [SEP]).  Word ids are uniform in
+    [word_lo, vocab_size) and never equal cls_id / sep_id (small vocabularies: clip_amd.precision's sample)."""
     rng = np.random.default_rng(seed)
     nseg = 2 * n_ctx + 1
     seg = _seg_lengths(rng, n_rows * nseg, sigma=sigma, hi=seg_hi).reshape(n_rows, nseg)
@@ -104,9 +106,12 @@ def packed_context_rows(n_rows, n_ctx=2, vocab_size=30522, max_len=256, seed=100
         raise ValueError("max_len too small for the focus sentence")
     lens = seg.sum(1) + overhead
     offsets = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-    flat = rng.integers(1000, vocab_size, int(offsets[-1]), dtype=np.int32)
-    flat[offsets[:-1]] = CLS_ID
+    flat = rng.integers(word_lo, vocab_size, int(offsets[-1]), dtype=np.int32)
+    if word_lo <= max(cls_id, sep_id):
+        alt = next(w for w in range(word_lo, vocab_size) if w not in (cls_id, sep_id))
+        flat[(flat == cls_id) | (flat == sep_id)] = alt
+    flat[offsets[:-1]] = cls_id
     # the [SEP] closing segment s of row r sits at offsets[r] + 1 + sum(seg[r, :s+1]) + s
     sep_pos = offsets[:-1, None] + 1 + np.cumsum(seg, 1) + np.arange(nseg)[None, :]
-    flat[sep_pos.ravel()] = SEP_ID
+    flat[sep_pos.ravel()] = sep_id
     return flat, offsets

@@ -57,6 +57,10 @@ class BertWordPieceTokenizer:
         self._special_re = re.compile("(" + "|".join(re.escape(t) for t in self.SPECIALS) + ")")
         self._word_cache = {}
 
+    def __len__(self):
+        """len(tokenizer) of HF's tokenizer: the vocabulary size (pretrain_tasks.py:250 draws random words from it)"""
+        return len(self.vocab)
+
     # ---- normaliser + pre-tokeniser
     def _normalize(self, text):
         out = []

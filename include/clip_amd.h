@@ -75,8 +75,14 @@ int clip_finalize_weights(clip_engine* e);
  *     RANGE: a weight beyond +-65504 is refused at load; an activation beyond it becomes inf and the
  *     logits NaN (never silently wrong).  BERT-base activations stay far inside it.  In this setting the
  *     LayerNorm output is kept ONCE (fp16, row-major: GEMM operand and residual are the same bits), where
- *     the bf16 setting keeps a bf16 operand copy and an fp16 residual copy. */
-enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1, CLIP_PRECISION_F16 = 2 };
+ *     the bf16 setting keeps a bf16 operand copy and an fp16 residual copy;
+ *   CLIP_PRECISION_F16R: fp16 operands as above with the RESIDUAL STREAM IN FP32: the N = hidden GEMMs
+ *     write fp32 pre-LayerNorm rows, the LayerNorm kernel leaves (mean, rstd), and the next residual add
+ *     recomputes the fp32 LayerNorm output in the GEMM epilogue (clip_gemm_bf16_lnres's form on fp16
+ *     operands) — the residual never passes through a 16-bit type.  Measured on the trained-like stress
+ *     goldens: rms logit error 3.8e-3 -> 2.6e-3, max 2.14e-2 -> 1.97e-2 (inside the 2e-2 budget), at
+ *     ~17 % less throughput than CLIP_PRECISION_F16 (more bytes per token; no LayerNorm fusion). */
+enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1, CLIP_PRECISION_F16 = 2, CLIP_PRECISION_F16R = 3 };
 int clip_set_precision(clip_engine* e, int32_t precision);
 
 /* Replaces _collect_focus_repr's index search (bert_model.py:52): for each packed sequence the
@@ -263,7 +269,10 @@ int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens);
  *               3 column-tile workgroups co-resident).  Sticky on the device: while it is set no later
  *               tile waits, so a void job ends quickly;
  *   bit 2 (4) = the row table of a forward was inconsistent (cu_seqlens[0] != 0, a row of < 1 or
- *               > max_seqlen tokens, cu_seqlens[n_seqs] != total_tokens).
+ *               > max_seqlen tokens, cu_seqlens[n_seqs] != total_tokens);
+ *   bit 3 (8) = a forward produced a non-finite logit (an fp16 activation beyond +-65504 in the F16 / F16R
+ *               settings, a NaN weight): `score > threshold` is False for NaN, so without this bit the
+ *               sentence would silently be missing from the output files.
  * While the word is non-zero every clip_forward_packed writes NaN logits: results of those calls are
  * void whether or not the caller polls. */
 int clip_poll_errors(clip_engine* e, int32_t* host_flags);

@@ -16,8 +16,13 @@ def main():
     if rc is not None:
         sys.exit(rc)
     dist, rank, world, device = launch.init_distributed(timeout_s=120)
-    if len(sys.argv) > 2 and sys.argv[2] == "fail" and rank == 1:
+    if len(sys.argv) > 2 and sys.argv[2] in ("fail", "hang") and rank == 1:
         sys.exit(7)
+    if len(sys.argv) > 2 and sys.argv[2] == "hang" and rank == 0:      # a rank that does not act on SIGTERM
+        import signal
+        import time
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(600)
     rng = np.random.default_rng(5)
     doc = np.sort(rng.integers(0, 200, 2000)).astype(np.int64)
     sent = np.arange(2000, dtype=np.int64)

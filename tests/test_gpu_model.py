@@ -224,6 +224,7 @@ def test_fused_layernorm_timeout_is_loud(monkeypatch):
     cfg = BertConfig(vocab_size=2000, hidden_size=512, num_hidden_layers=3, num_attention_heads=8, intermediate_size=1024)
     model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=16384, max_seqs=512)
     model.load_state_dict(procedural_state_dict(cfg, 3))
+    model.set_precision("bf16")      # the switch acts on the fused flow of a fixed setting (auto would meet it while calibrating)
     model.to("cuda").eval()
     model.set_sep_token_id(102); model.set_n_context_sentences(2); model.set_task("multilabel")
     rows = synth.context_rows(300, 2, cfg.vocab_size, max_len=96, seed=11)       # several row panels per GEMM
@@ -256,6 +257,7 @@ def test_fused_layernorm_epoch_wrap_is_handled(monkeypatch):
             monkeypatch.setenv("CLIP_AMD_TEST_EPOCH_START", start)
         model = BertSequenceMultilabelClassificationContext(cfg, max_tokens=8192, max_seqs=512)
         model.load_state_dict(procedural_state_dict(cfg, 3))
+        model.set_precision("bf16")
         model.to("cuda").eval()
         model.set_sep_token_id(102); model.set_n_context_sentences(2); model.set_task("multilabel")
         res = scoring.BulkScorer(model, keep_probs=True, tokens_per_step=4096).score(rows)

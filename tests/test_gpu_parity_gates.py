@@ -23,7 +23,8 @@ TTP = np.array([0.18, 0.6, 0.11, 0.32, 0.1, 0.1, 0.18])                        #
 
 def _model(cfg, sd, n_ctx, precision, tokens=32768):
     m = args_to_model(n_ctx)(cfg, max_tokens=tokens, max_seqs=4096)
-    m.set_precision(precision)
+    if precision is not None:           # None: the default of the classes, 'auto'
+        m.set_precision(precision)
     m.load_state_dict(sd)
     m.to("cuda").eval()
     if n_ctx:
@@ -60,25 +61,21 @@ def _logits(cfg, sd, rows, n_ctx, precision, batch_size):
 
 # Operand rounding is RELATIVE: the logit error of a 16-bit-operand forward scales with the logit spread.
 # Measured floor of bf16 operands (tools/rounding_study.py: weights, LayerNorm outputs, GELU outputs and
-# attention outputs each rounded to 8 bits): ~0.5 % rms of the logit spread.  That is inside 2e-2 while
-# logits stay within +-2 (procedural weights: test_gpu_model.py asserts 2e-2 absolute there) and cannot be
-# for logits of +-7; fp16 operands (same MFMA rate, CLIP_PRECISION_F16) round 8x finer.  On the
-# trained-like goldens the budget is therefore stated as
-#     |logit - ref| <= 2e-2 * max(1, |ref| / BAND),   BAND = 2.5
-# i.e. 2e-2 ABSOLUTE across the decision band of every threshold the reference ships (logit(0.1) = -2.2 ..
-# logit(0.6) = 0.41) and 2e-2 relative where the sigmoid saturates.  Measured on base_ctx_stress (logits
-# -6.7 .. +7.9): fp32 check mode 3.5e-5; f16 2.1e-2 in that form (2.2e-2 absolute: AT the budget, not
-# inside it — every 11-bit rounding point, weights, LayerNorm output, fp16 residual, q/k/v, contributes
-# equally; tools/rounding_study.py with OPERAND=f16); bf16 5.1e-2 (6.2e-2 absolute: 2.5x OVER the budget).
-# The asserts below are those measurements with 20 % head-room — regression guards, not a claim that the
-# 2e-2 budget holds for 16-bit operands on logits of +-8; the thresholded-label agreement above is the
-# criterion that is met by f16 (>= 99.97 %); bf16 reaches 99.79-99.93 % on these weights.
+# attention outputs each rounded to 8 bits): ~0.5 % rms of the logit spread — inside 2e-2 while logits stay
+# within +-2 (procedural weights: test_gpu_model.py asserts 2e-2 absolute there), 3x outside it on the
+# trained-like stress goldens (logits -6.7 .. +7.9).  fp16 operands (same MFMA rate) round 8x finer: 2.1e-2
+# on base_ctx_stress with an fp16 residual copy ('f16'), 1.97e-2 with the residual stream kept in fp32 ('f16r').
+# The criteria are therefore asserted, at north_star's own numbers, on the setting the DEFAULT (precision
+# 'auto', clip_amd/precision.py) selects and on 'f16r'; the asserts on fixed 'bf16' / 'f16' where they miss
+# the bar are labelled regression guards.
 BAND = 2.5
 
 
 @pytest.mark.parametrize("kind", ["fixed256", "c5_varlen"])
-@pytest.mark.parametrize("weights,precision", [("procedural", "bf16"), ("procedural", "f16"),
-                                               ("trained_like", "f16"), ("trained_like", "bf16")])
+@pytest.mark.parametrize("weights,precision", [("procedural", "auto"), ("trained_like", "auto"),
+                                               ("procedural", "bf16"), ("procedural", "f16"),
+                                               ("trained_like", "f16"), ("trained_like", "f16r"),
+                                               ("trained_like", "bf16")])
 def test_thresholded_label_agreement_at_scale(kind, weights, precision):
     cfg = BertConfig()
     sd = (trained_like_state_dict if weights == "trained_like" else procedural_state_dict)(cfg, 0)
@@ -87,7 +84,19 @@ def test_thresholded_label_agreement_at_scale(kind, weights, precision):
     else:
         flat, off = synth.packed_context_rows(4096, 2, cfg.vocab_size, 512, seed=78, sigma=0.9, seg_hi=200)
         rows = scoring.PackedRows(flat, off)
-    p16 = _probs(cfg, sd, rows, 2, precision)
+    if precision == "auto":
+        # the DEFAULT path: no set_precision call at all — BulkScorer calibrates on these rows
+        m = _model(cfg, sd, 2, None)
+        p16 = scoring.BulkScorer(m, keep_probs=True).score(rows).probs
+        print(f"{kind}/{weights}: auto selected {m.resolved_precision}: {m.precision_report['candidates']}")
+        assert m.precision == "auto"
+        if weights == "procedural":
+            assert m.resolved_precision == "bf16"
+        else:
+            assert m.resolved_precision in ("f16", "f16r")      # bf16 must have been measured out
+        m._drop_engine()
+    else:
+        p16 = _probs(cfg, sd, rows, 2, precision)
     p32 = _probs(cfg, sd, rows, 2, "fp32")
     for name, thr in (("dnote", DNOTE), ("ttp", TTP)):
         agree, n_bad = _agreement(p16, p32, thr)
@@ -95,23 +104,23 @@ def test_thresholded_label_agreement_at_scale(kind, weights, precision):
         if not (weights == "trained_like" and precision == "bf16"):
             assert agree >= 0.999
         else:
-            # bf16 operands on trained-like weights: measured 99.79-99.93 % (tools/agreement_ab.py: three row
-            # seeds x two library builds with the same rms logit error, 19-60 of 28672 decisions differ) —
-            # BELOW the 99.9 % bar on the ttp thresholds; the setting for such checkpoints is f16 (asserted
-            # above).  This line only guards against regressions.
+            # REGRESSION GUARD, not the criterion: fixed bf16 operands on trained-like weights measure 99.79-99.93 %
+            # (tools/agreement_ab.py) — below the 99.9 % bar on the ttp thresholds, which is why the default is
+            # 'auto' and measures bf16 out for such a checkpoint (asserted above)
             assert agree >= 0.997
 
 
 @pytest.mark.parametrize("name", ["base_ctx_stress", "base_sent_stress"])
 def test_trained_like_stress_golden(golden, name):
     """Reference logits beyond +-6 (base_ctx_stress: -6.7 .. +7.9), LayerNorm gamma outliers, outlier
-    hidden dimensions, heavy-tailed embeddings; goldens from the imported reference."""
+    hidden dimensions, heavy-tailed embeddings; goldens from the imported reference.  north_star's 2e-2 ABSOLUTE
+    is asserted for the setting the default ('auto') selects and for 'f16r'; 1e-4 for the fp32 check mode."""
     g = golden(name)
     sd = golden_state_dict(g)
     ref = g["ref_logits"]
     err = {}
-    for precision in ("fp32", "f16", "bf16"):
-        logits = _logits(g["cfg"], sd, g["rows"], g["n_ctx"], precision, g["batch_size"])
+    for precision in ("fp32", "auto", "f16r", "f16", "bf16"):
+        logits = _logits(g["cfg"], sd, g["rows"], g["n_ctx"], None if precision == "auto" else precision, g["batch_size"])
         assert np.isfinite(logits).all()
         err[precision] = np.abs(logits - ref)
         print(f"{name}/{precision}: max |logit - ref| = {err[precision].max():.3e}, "
@@ -122,10 +131,38 @@ def test_trained_like_stress_golden(golden, name):
                 assert _agreement(p.astype(np.float32), g["ref_probs"], thr)[0] == 1.0
     # fp32 check mode: 1e-4, relative above |logit| = 1 (fp32 itself resolves 1e-6 of a logit of 8)
     assert (err["fp32"] / np.maximum(1, np.abs(ref))).max() < 1e-4
+    assert err["auto"].max() < 2e-2            # the default path, north_star's tolerance as stated
+    assert err["f16r"].max() < 2e-2
+    # regression guards for the fixed settings that miss 2e-2 absolute on base_ctx_stress (measured 2.14e-2 / 6.4e-2)
     assert (err["f16"] / np.maximum(1, np.abs(ref) / BAND)).max() < 2.5e-2
     assert (err["bf16"] / np.maximum(1, np.abs(ref) / BAND)).max() < 6e-2
-    if name == "base_sent_stress":          # logits -2.9 .. +0.4: the absolute budget, f16
+    if name == "base_sent_stress":          # logits -2.9 .. +0.4
         assert err["f16"].max() < 2e-2
+
+
+def test_auto_refuses_f16_when_an_activation_leaves_its_range():
+    """Weights scaled so that fp16 activations overflow: auto must not select a setting whose sampled scores are
+    non-finite, a fixed 'f16' must raise instead of silently dropping sentences (scoring.py), bf16 still scores."""
+    cfg = BertConfig(vocab_size=2000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+    sd = procedural_state_dict(cfg, 9)
+    for k in ("bert.encoder.layer.0.intermediate.dense.weight", "bert.encoder.layer.0.intermediate.dense.bias"):
+        sd[k] = sd[k] * 1.0e5      # FFN intermediate of ~+-3e4 rms: beyond 65504 in places; the next LayerNorm rescales
+    sd["bert.encoder.layer.0.output.dense.weight"] = sd["bert.encoder.layer.0.output.dense.weight"] * 1e-4
+    rows = synth.context_rows(256, 2, cfg.vocab_size, max_len=96, seed=5)
+    m = _model(cfg, sd, 2, "f16", tokens=16384)
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        scoring.BulkScorer(m).score(rows)
+    ids, mask = O.pad_batch(rows[:8])          # ... and so does the nn.Module forward
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=O.token_type_ids_from_seps(ids, 102, 2).cuda())
+    m._drop_engine()
+    m = _model(cfg, sd, 2, None, tokens=16384)
+    res = scoring.BulkScorer(m, keep_probs=True).score(rows)
+    rep = m.precision_report
+    print(rep)
+    assert "refused" in rep["candidates"]["f16"] and "refused" in rep["candidates"]["f16r"]
+    assert m.resolved_precision == "bf16" and np.isfinite(res.probs).all()
+    m._drop_engine()
 
 
 @pytest.mark.parametrize("name", ["tiny_ctx", "tiny_sent", "base_ctx", "base_sent"])
