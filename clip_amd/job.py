@@ -223,9 +223,12 @@ def main(argv=None):
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
     if not int(fin.item()):
         if rank == 0:
+            import resource
             print(json.dumps({"job": args.config, "finished": False, "state": args.state,
                               "rows_so_far_rank0": state.rows, "seconds_this_invocation": round(t_score, 3),
-                              "invocations": state.invocations}), flush=True)
+                              "seconds_so_far": round(t_score + state.seconds, 3), "invocations": state.invocations,
+                              "peak_host_rss_mb_rank0": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)}),
+                  flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return None

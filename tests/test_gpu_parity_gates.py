@@ -140,7 +140,7 @@ def test_trained_like_stress_golden(golden, name):
         assert err["f16"].max() < 2e-2
 
 
-def test_auto_refuses_f16_when_an_activation_leaves_its_range():
+def test_auto_refuses_f16_when_an_activation_leaves_its_range(monkeypatch):
     """Weights scaled so that fp16 activations overflow: auto must not select a setting whose sampled scores are
     non-finite, a fixed 'f16' must raise instead of silently dropping sentences (scoring.py), bf16 still scores."""
     cfg = BertConfig(vocab_size=2000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
@@ -156,11 +156,15 @@ def test_auto_refuses_f16_when_an_activation_leaves_its_range():
     with pytest.raises(FloatingPointError, match="non-finite"):
         m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=O.token_type_ids_from_seps(ids, 102, 2).cuda())
     m._drop_engine()
+    # auto tries the candidates fastest first and would stop at bf16 here; with the fp16 settings tried first
+    # (the order a caller with an fp16-only accuracy need would see) both must be refused, not selected
+    from clip_amd import precision as P
+    monkeypatch.setattr(P, "CANDIDATES", ("f16", "f16r", "bf16"))
     m = _model(cfg, sd, 2, None, tokens=16384)
     res = scoring.BulkScorer(m, keep_probs=True).score(rows)
     rep = m.precision_report
     print(rep)
-    assert "refused" in rep["candidates"]["f16"] and "refused" in rep["candidates"]["f16r"]
+    assert "non-finite" in rep["candidates"]["f16"]["refused"] and "non-finite" in rep["candidates"]["f16r"]["refused"]
     assert m.resolved_precision == "bf16" and np.isfinite(res.probs).all()
     m._drop_engine()
 
