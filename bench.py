@@ -29,7 +29,7 @@ from clip_amd.weights import procedural_state_dict  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0      # HBM3E, same guide
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 DNOTE_THRESHS = np.array([0.44, 0.31, 0.24, 0.17, 0.46, 0.35000000000000003, 0.43])
 
 
@@ -244,7 +244,7 @@ def main():
             pass
         mfma_busy = None      # MFMA busy cycles / kernel cycles of the dominant kernel, from an SQ PMC pass kept under profiles/
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_util.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.json")) as fh:
                 mfma_busy = json.load(fh)["gemm8_kernel<1, false, false>"]["mfma_utilisation"]
         except (OSError, KeyError, ValueError):
             pass
@@ -293,17 +293,18 @@ def main():
             res["kernel_ms_per_step"] = {k: round(ms[i] / args.steps, 4) for i, k in enumerate(_lib.KINDS)}
             res["roofline_by_kernel"] = roofline_by_kernel({k: ms[i] / args.steps for i, k in enumerate(_lib.KINDS)},
                                                            batches[0]["lens"], cfg, args.precision, args.steps)
-        if world == 1:
+        if world == 1 and not args.no_cpu_baseline:
+            # (skipped with --no-cpu-baseline: profile runs must see the benchmark's own launches only)
             # what precision='auto' (the default everywhere but here: the headline metric is bf16) selects for these
             # weights, with the numbers it measured (clip_amd/precision.py), outside the timed region
             probe = BertSequenceMultilabelClassificationContext(cfg, max_tokens=32768, max_seqs=1024)
             probe._sd = model._sd
             probe.to(device)
             probe.set_sep_token_id(102); probe.set_n_context_sentences(n_ctx)
-            probe.calibrate_precision(all_rows[:512], log=False)
+            probe.calibrate_precision(all_rows, log=False)
             rep = probe.precision_report
             res["precision_auto"] = {"selected": rep["selected"], "meets_criteria": rep["meets_criteria"],
-                                     "sample_rows": rep["sample_rows"],
+                                     "sample_rows": rep["sample_rows"], "seconds": rep["seconds"],
                                      "candidates": {k: {kk: vv for kk, vv in v.items() if kk != "rms_logit_err"}
                                                     for k, v in rep["candidates"].items()}}
             probe._drop_engine()

@@ -193,9 +193,9 @@ def main(argv=None):
         model.set_n_context_sentences(args.n_context_sentences)                        # :75
     model.set_task(args.task)                                                          # :80
     if args.precision == "auto" and N:
-        # measured on 8 runs of 64 rows spread over the WHOLE input — the same sample on every rank, so every
+        # measured on 8 runs of 256 rows spread over the WHOLE input — the same sample on every rank, so every
         # rank reaches the same setting without a message
-        per = min(64, max(N // 8, 1))
+        per = min(256, max(N // 8, 1))
         starts = sorted({int(x) for x in (np.arange(8) * (N - per) // 7)})
         blocks = [r for r, _, _ in rows_of([(a, min(a + per, N)) for a in starts])]
         lens = np.concatenate([r.lens for r in blocks]).astype(np.int64)

@@ -7,7 +7,7 @@ setting meets them depends on the checkpoint (logits of +-2: bf16 does; logits o
 gamma outliers: bf16 misses both, tests/test_gpu_parity_gates.py).  Nothing in the reference chooses a
 precision (apply_bert_unlabeled.py:72 runs fp32 torch), so the build measures instead of assuming:
 
-  1. a sample (up to SAMPLE_ROWS rows of the caller's own input, else synthetic rows of the model's
+  1. a sample (up to SAMPLE_ROWS = 2048 rows of the caller's own input, else synthetic rows of the model's
      layout) is scored in the fp32 check mode (pinned to the reference at <= 1e-4 on every golden);
   2. the candidates are tried fastest first — bf16, f16, f16r (fp16 operands, fp32 residual stream) —
      and the first one with   max |logit - fp32| <= 2e-2   AND   agreement >= 99.9 % on BOTH threshold
@@ -31,7 +31,7 @@ from .constants import DNOTE_LABEL_THRESHS, TTP_LABEL_THRESHS
 CANDIDATES = ("bf16", "f16", "f16r")
 MAX_ABS_LOGIT = 2e-2          # BASELINE.json north_star
 MIN_AGREEMENT = 0.999         # BASELINE.json north_star
-SAMPLE_ROWS = 512
+SAMPLE_ROWS = 2048         # 14 336 decisions with 7 labels: 99.9 % leaves room for 14 flips (512 rows left room for 3: noise)
 _CACHE = {}                   # (weights fingerprint, model kind, sample fingerprint) -> report
 
 
@@ -126,6 +126,8 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
         thr_sets = {"dnote": DNOTE_LABEL_THRESHS, "ttp": TTP_LABEL_THRESHS}
     if label_threshs is not None:
         thr_sets["caller"] = np.asarray(label_threshs, np.float64)
+    import time
+    t0 = time.perf_counter()
     ref_logits, ref_probs = _score(model, "fp32", sample, max_tokens, max_seqs)
     report = {"sample_rows": int(len(sample)), "sample_tokens": int(sample.offsets[-1]), "sample": source,
               "criteria": {"max_abs_logit": MAX_ABS_LOGIT, "min_agreement": MIN_AGREEMENT},
@@ -159,6 +161,7 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
             raise FloatingPointError("precision='auto': no 16-bit setting gives finite scores on the sample; "
                                      "use precision='fp32' for this checkpoint")
         report["selected"] = finite[-1]
+    report["seconds"] = round(time.perf_counter() - t0, 3)
     _CACHE[key] = report
     if log is not False:
         print(format_report(report), file=log or sys.stderr, flush=True)
@@ -177,4 +180,4 @@ def format_report(report):
     tail = "" if report["meets_criteria"] else \
         " (NO 16-bit setting meets 2e-2 / 99.9 % on this checkpoint: the most precise one is used; precision='fp32' is exact)"
     return (f"[clip_amd] precision auto -> {report['selected']}{tail}; {report['sample_rows']} {report['sample']} "
-            f"vs the fp32 check mode: " + "; ".join(parts))
+            f"vs the fp32 check mode ({report.get('seconds', 0):.1f} s): " + "; ".join(parts))

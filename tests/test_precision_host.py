@@ -31,7 +31,7 @@ def test_spread_sample_is_deterministic_and_covers_the_input():
     off = np.concatenate(([0], np.cumsum(lens)))
     rows = PackedRows(np.arange(off[-1], dtype=np.int32), off)
     a, b = P.spread_sample(rows), P.spread_sample(rows)
-    assert len(a) == 512 and np.array_equal(a.flat, b.flat) and np.array_equal(a.offsets, b.offsets)
+    assert len(a) == P.SAMPLE_ROWS == 2048 and np.array_equal(a.flat, b.flat) and np.array_equal(a.offsets, b.offsets)
     assert a.flat[0] == 0 and a.flat[-1] == rows.flat[-1]          # first and last rows are in it
     small = PackedRows(rows.flat[:off[100]], off[:101])
     assert P.spread_sample(small) is small

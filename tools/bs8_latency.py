@@ -19,6 +19,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cfg = BertConfig()
 m = args_to_model(2)(cfg, max_tokens=131072, max_seqs=16384)
 m.load_state_dict(procedural_state_dict(cfg, 0))
+m.set_precision(os.environ.get("PRECISION", "bf16"))
 m.to("cuda").eval()
 m.set_sep_token_id(102); m.set_n_context_sentences(2); m.set_task("multilabel")
 flat, off = synth.packed_context_rows(N, 2, cfg.vocab_size, 256, seed=5)
