@@ -93,9 +93,16 @@ class _EngineModel:
                                    "clip_amd has no CPU execution path")
             if self._sd is None:
                 raise RuntimeError("no weights loaded (from_pretrained / load_state_dict)")
-            self.precision_report = P.choose_precision(self, rows, label_threshs, log)
+            self.precision_report, clone = P.choose_precision(self, rows, label_threshs, log)
             self._drop_engine()
             self.resolved_precision = self.precision_report["selected"]
+            if clone is not None:
+                # the candidate that passed was built with this model's workspace size: adopt its engine
+                if (clone.max_tokens, clone.max_seqs, clone.device) == (self.max_tokens, self.max_seqs, self.device):
+                    self._engine, clone._engine = clone._engine, None
+                    if hasattr(clone, "_trim_off"):
+                        self._trim_off = clone._trim_off
+                clone._drop_engine()
         return self.resolved_precision
 
     # ---- construction (test_load.py:21, apply_bert_unlabeled.py:65-70,78-79)

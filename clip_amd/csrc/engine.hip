@@ -2,7 +2,9 @@
 // workspace; clip_forward_packed chains the kernels of one BERT(+Context) forward on one stream.
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -124,10 +126,27 @@ int upload_f32(clip_engine* e, const std::vector<float>& h, float** d) {
   return CLIP_OK;
 }
 
+// fn(begin, end) over [0, n) on up to 8 host threads (the weight roundings: 110 M elements per engine build)
+template <class F>
+void parallel_ranges(size_t n, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = n < (1u << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+  if (nt <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (size_t t = 0; t < nt; ++t) {
+    const size_t a = t * per, b = std::min(n, a + per);
+    if (a < b) th.emplace_back([=] { fn(a, b); });
+  }
+  for (auto& x : th) x.join();
+}
+
 int upload_bf16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scale_first = 1.f,
                 size_t n_first = 0) {
   std::vector<uint16_t> tmp(n);
-  for (size_t i = 0; i < n; ++i) tmp[i] = host_f32_to_bf16(i < n_first ? h[i] * scale_first : h[i]);
+  parallel_ranges(n, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) tmp[i] = host_f32_to_bf16(i < n_first ? h[i] * scale_first : h[i]);
+  });
   int rc = dev_alloc(e, (void**)d, n * 2);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*d, tmp.data(), n * 2, hipMemcpyHostToDevice));
@@ -136,13 +155,18 @@ int upload_bf16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scal
 
 int upload_f16(clip_engine* e, const float* h, size_t n, bf16_t** d, float scale_first, size_t n_first) {
   std::vector<uint16_t> tmp(n);
-  for (size_t i = 0; i < n; ++i) {
-    const float v = i < n_first ? h[i] * scale_first : h[i];
-    if (std::fabs(v) > 65504.f)
-      return fail(CLIP_ERR_ARG, "a weight (%g) is outside fp16's range: use CLIP_PRECISION_BF16 for this checkpoint", v);
-    const _Float16 hv = (_Float16)v;  // round to nearest even
-    memcpy(&tmp[i], &hv, 2);
-  }
+  std::atomic<size_t> bad{n};   // index of a weight outside fp16's range (n: none)
+  parallel_ranges(n, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; ++i) {
+      const float v = i < n_first ? h[i] * scale_first : h[i];
+      if (!(std::fabs(v) <= 65504.f)) { bad.store(i); return; }
+      const _Float16 hv = (_Float16)v;  // round to nearest even
+      memcpy(&tmp[i], &hv, 2);
+    }
+  });
+  if (bad.load() < n)
+    return fail(CLIP_ERR_ARG, "a weight (%g) is outside fp16's range: use CLIP_PRECISION_BF16 for this checkpoint",
+                (double)h[bad.load()]);
   int rc = dev_alloc(e, (void**)d, n * 2);
   if (rc) return rc;
   HIP_TRY(hipMemcpy(*d, tmp.data(), n * 2, hipMemcpyHostToDevice));

@@ -95,18 +95,24 @@ def _clone(model, precision, max_tokens, max_seqs):
     return m
 
 
-def _score(model, precision, sample, max_tokens, max_seqs):
+def _score(model, precision, sample, max_tokens, max_seqs, keep=False):
+    """(logits, probs, clone): the clone still holds its engine when keep (the caller adopts or drops it)"""
     from .scoring import BulkScorer
     m = _clone(model, precision, max_tokens, max_seqs)
     try:
         res = BulkScorer(m, keep_probs=True, keep_logits=True).score(sample)
-    finally:
+    except BaseException:
         m._drop_engine()
-    return res.logits, res.probs
+        raise
+    if not keep:
+        m._drop_engine()
+    return res.logits, res.probs, (m if keep else None)
 
 
 def choose_precision(model, rows=None, label_threshs=None, log=None):
-    """Measure the candidates on a sample and return the report dict (key 'selected')."""
+    """Measure the candidates on a sample.  Returns (report dict with key 'selected', clone or None): the clone is
+    the candidate model that passed, built with the caller's own workspace size and still holding its engine, so
+    that the caller adopts that engine instead of building the same one again."""
     from . import _lib
     from .scoring import PackedRows
     if rows is not None and not isinstance(rows, PackedRows):
@@ -117,7 +123,7 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
            getattr(model, "sep_token_id", None), hashlib.blake2b(sample.flat.tobytes(), digest_size=16).hexdigest(),
            None if label_threshs is None else tuple(np.asarray(label_threshs, np.float64).tolist()))
     if key in _CACHE:
-        return _CACHE[key]
+        return _CACHE[key], None
     max_tokens = max(32768, int(sample.lens.max()))
     max_seqs = max(1024, min(len(sample), 4096))
     L = model.num_labels
@@ -128,16 +134,18 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
         thr_sets["caller"] = np.asarray(label_threshs, np.float64)
     import time
     t0 = time.perf_counter()
-    ref_logits, ref_probs = _score(model, "fp32", sample, max_tokens, max_seqs)
+    ref_logits, ref_probs, _ = _score(model, "fp32", sample, max_tokens, max_seqs)
     report = {"sample_rows": int(len(sample)), "sample_tokens": int(sample.offsets[-1]), "sample": source,
               "criteria": {"max_abs_logit": MAX_ABS_LOGIT, "min_agreement": MIN_AGREEMENT},
               "candidates": {}, "selected": None, "meets_criteria": False}
     finite = []
+    adopted = None
     for cand in CANDIDATES:
         entry = {}
         report["candidates"][cand] = entry
         try:
-            logits, probs = _score(model, cand, sample, max_tokens, max_seqs)
+            logits, probs, clone = _score(model, cand, sample, max(model.max_tokens, int(sample.lens.max())),
+                                          max(model.max_seqs, 1), keep=True)
         except _lib.ClipError as exc:               # a weight outside the operand range (clip_finalize_weights)
             if "range" not in str(exc):
                 raise
@@ -155,7 +163,9 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
                                all(a >= MIN_AGREEMENT for a in entry["agreement"].values()))
         if entry["passes"]:
             report["selected"], report["meets_criteria"] = cand, True
+            adopted = clone
             break
+        clone._drop_engine()
     if report["selected"] is None:
         if not finite:
             raise FloatingPointError("precision='auto': no 16-bit setting gives finite scores on the sample; "
@@ -165,7 +175,7 @@ def choose_precision(model, rows=None, label_threshs=None, log=None):
     _CACHE[key] = report
     if log is not False:
         print(format_report(report), file=log or sys.stderr, flush=True)
-    return report
+    return report, adopted
 
 
 def format_report(report):

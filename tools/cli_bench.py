@@ -53,5 +53,31 @@ try:
         dt = time.perf_counter() - t0
         print(f"{name}: {dt:.2f} s, {N / dt:,.0f} sentences/s", flush=True)
     print("kept rows:", sum(1 for _ in open(os.path.join(run, "ttp_doc_sents.csv"))))
+    gpus = int(os.environ.get("CLI_GPUS", "0"))
+    if gpus > 1:
+        # the multi-rank command line as a user starts it (fresh processes; ranks share the card over gloo on a
+        # one-GPU box — a rehearsal of the code path and of the token balance, not a throughput measurement)
+        import hashlib
+        import subprocess
+        one = hashlib.sha256(open(os.path.join(run, "ttp_doc_sents.csv"), "rb").read()).hexdigest()
+        one_top = hashlib.sha256(open(os.path.join(run, "ttp_top50000.csv"), "rb").read()).hexdigest()
+        env = dict(os.environ, CLIP_AMD_TIMING="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if torch.cuda.device_count() < gpus:
+            env["CLIP_AMD_FUSED_LN"] = "0"
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        t0 = time.perf_counter()
+        p = subprocess.run([sys.executable, "-u", "-m", "clip_amd.apply_bert_unlabeled", csv_path, model_dir,
+                            os.path.join(run, "w.safetensors"), "--n_context_sentences", "2", "--topk", "50000",
+                            "--gpus", str(gpus)], cwd=ROOT, env=env, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        print(p.stderr[-12000:])
+        print(p.stdout[-500:])
+        assert p.returncode == 0
+        two = hashlib.sha256(open(os.path.join(run, "ttp_doc_sents.csv"), "rb").read()).hexdigest()
+        two_top = hashlib.sha256(open(os.path.join(run, "ttp_top50000.csv"), "rb").read()).hexdigest()
+        print(f"--gpus {gpus} (CSV -> scores + top-k, process start to exit): {dt:.2f} s; files identical to one rank's "
+              f"(fused-LayerNorm flow {'off in the ranks: bits may differ' if env.get('CLIP_AMD_FUSED_LN') == '0' else 'on'}): "
+              f"ttp_doc_sents {one == two}, top-k {one_top == two_top}", flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
