@@ -64,3 +64,38 @@ def test_graded_chunk_bounds():
     assert sizes[0] <= 256 and max(sizes) <= 4096 and max(sizes) > 2048              # small first, grows to chunk_rows
     assert columnar.graded_chunk_bounds(d, 100, first_rows=256) == columnar.chunk_bounds(d, 100)
     assert columnar.graded_chunk_bounds(d[:0], 100) == []
+
+
+def test_merge_parts_equals_the_whole(tmp_path):
+    """The ranks' --save_rows parts (consecutive row ranges) joined by merge_parts = the corpus saved in one go."""
+    rows, d, s = _corpus(3000, seed=9)
+    columnar.save_rows(str(tmp_path / "whole"), rows, d, s, n_context_sentences=2, sep_token_id=102)
+    cuts = [0, 700, 700, 2100, 3000]                      # an empty part too (a rank without documents)
+    parts = []
+    for k, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        o = rows.offsets[a:b + 1]
+        columnar.save_rows(str(tmp_path / f"p{k}"), PackedRows(rows.flat[o[0]:o[-1]], o - o[0]), d[a:b], s[a:b],
+                           n_context_sentences=2, sep_token_id=102)
+        parts.append(str(tmp_path / f"p{k}"))
+    columnar.merge_parts(parts, str(tmp_path / "joined"), n_context_sentences=2, sep_token_id=102)
+    w, j = columnar.ColumnarCorpus(str(tmp_path / "whole")), columnar.ColumnarCorpus(str(tmp_path / "joined"))
+    for k in columnar.FILES:
+        assert np.array_equal(getattr(w, k), getattr(j, k)) and getattr(w, k).dtype == getattr(j, k).dtype
+    assert w.meta == j.meta
+    import os
+    assert not any(os.path.exists(p) for p in parts)      # the parts are gone
+
+
+def test_rank_ranges_are_whole_documents_balanced_by_weight():
+    """What every rank of the CLI computes from the document index alone (clip_amd/apply_bert_unlabeled.py): a
+    partition into contiguous ranges that end on document boundaries, within one document of an even token share."""
+    from clip_amd import topk
+    rows, d, s = _corpus(20000, seed=3)
+    w = rows.lens.astype(np.int64)
+    for world in (2, 3, 8):
+        r = [topk.shard_documents(d, w, world, k) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == len(d) and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        for a, b in r:
+            assert b == len(d) or a == b or d[b] != d[b - 1]
+        share = np.array([w[a:b].sum() for a, b in r]) * world / w.sum()
+        assert np.abs(share - 1).max() < 0.02

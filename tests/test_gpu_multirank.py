@@ -54,9 +54,10 @@ def test_job_two_ranks_topk_file_identical_to_one_rank(tmp_path):
 
 
 def test_cli_two_ranks_files_identical_to_one_rank(tmp_path):
-    """python -m clip_amd.apply_bert_unlabeled --gpus 2: rank 0 tokenises once and writes the columnar directory,
-    both ranks memory-map it, chunk c belongs to rank c mod 2, CSV parts are concatenated in chunk order and the
-    top-k is one all-gather: ttp_doc_sents.csv and the top-k file must be the one-rank files byte for byte."""
+    """python -m clip_amd.apply_bert_unlabeled --gpus 2: each rank reads the document index, takes its own contiguous
+    range of whole documents and tokenises + scores it; CSV parts are concatenated in (rank, piece) order and the
+    top-k is one all-gather: ttp_doc_sents.csv and the top-k file must be the one-rank files byte for byte — and so
+    must the columnar directory --save_rows leaves (the ranks' parts joined by rank 0)."""
     import shutil
     from clip_amd.config import BertConfig
     from clip_amd.weights import procedural_state_dict
@@ -73,11 +74,14 @@ def test_cli_two_ranks_files_identical_to_one_rank(tmp_path):
         torch.save(sd, run / "w.pth")
         p = subprocess.run([sys.executable, "-u", "-m", "clip_amd.apply_bert_unlabeled", os.path.join(G, "notes_synth.csv"),
                             str(model_dir), str(run / "w.pth"), "--n_context_sentences", "2", "--threshold", "0.3",
-                            "--topk", "25", "--tokens_per_step", "4096", "--chunk_rows", "8", *extra],
+                            "--topk", "25", "--tokens_per_step", "4096", "--chunk_rows", "8", "--save_rows", str(run / "rows"),
+                            *extra],
                            cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
         assert f"{2 if extra else 1} rank(s)" in p.stdout
         outs.append(((run / "ttp_doc_sents.csv").read_bytes(), (run / "ttp_top25.csv").read_bytes()))
-        assert not [f for f in os.listdir(run) if ".chunk" in f]          # parts merged and removed
-    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+        assert not [f for f in os.listdir(run) if ".chunk" in f or ".part" in f]          # parts merged and removed
+        import numpy as np
+        outs[-1] += tuple(np.load(run / "rows" / f"{k}.npy").tobytes() for k in ("flat", "offsets", "doc_ids", "sent_ixs"))
+    assert outs[0] == outs[1]
     assert outs[0][0].count(b"\n") == 33 and outs[0][1].count(b"\n") == 26     # 33 rows in >= 4 chunks of whole documents
