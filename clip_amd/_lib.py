@@ -51,6 +51,7 @@ SIGNATURES = {
     "clip_gemm_bf16_lnout_noalloc": [_p, _p, _p, _p, _i32, _p, _p, _f, _p, _p, _p,
                                      _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f16_lnout_inplace": [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, C.c_uint32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    "clip_gemm_f16_lnout_res32": [_p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, C.c_uint32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_gemm_f32": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],
     "clip_attention_varlen_f16": [_p, _p, _p, _i32, _i32, _i32, _i32, _p],

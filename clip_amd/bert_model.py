@@ -72,7 +72,7 @@ class _EngineModel:
         (clip_amd/precision.py; the choice is printed and kept in .precision_report).  Or fixed: 'bf16' (bf16
         operands; within 2e-2 on benign weights, logits of +-2), 'f16' (fp16 operands at the same speed, 1/8 of
         bf16's operand rounding, at the price of fp16's range), 'f16r' (fp16 operands + fp32 residual stream:
-        inside 2e-2 on the trained-like stress goldens, ~17 % slower) or 'fp32' (check mode: the same kernels on
+        inside 2e-2 on the trained-like stress goldens, ~7 % slower) or 'fp32' (check mode: the same kernels on
         fp32 operands, within 1e-4; ~16x slower).  Rebuilds the engine on next use."""
         if precision not in ("auto",) + tuple(_lib.PRECISIONS):
             raise ValueError(f"precision must be 'auto', 'bf16', 'f16', 'f16r' or 'fp32', not {precision!r}")

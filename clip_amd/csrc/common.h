@@ -101,6 +101,17 @@ __host__ __device__ __forceinline__ size_t xres_tiled_offset(int row, int col, i
   return ((tile * 8 + wave) * 8 + blk) * 1024 + ((c >> 5) & 1) * 512 + lane * 8 + ((c >> 4) & 1) * 4 + (c & 3);
 }
 
+// The same tile order for an fp32 residual stream (CLIP_PRECISION_F16R): inside a wave's (blk, nh) piece the two
+// 16-column blocks i = 0, 1 come one after the other, so that a lane's four values of a block are one 16-byte access
+// and a wave's access is 1 KiB contiguous:   offset = ((tile * 8 + wave) * 8 + blk) * 1024 + nh * 512 + i * 256 + lane * 4 + e
+__host__ __device__ __forceinline__ size_t xres32_tiled_offset(int row, int col, int tiles_n) {
+  const int r = row & 255, c = col & 255;
+  const size_t tile = (size_t)(row >> 8) * tiles_n + (col >> 8);
+  const int wave = ((r >> 6) & 1) * 4 + (c >> 6), blk = (r >> 7) * 4 + ((r >> 4) & 3);
+  const int lane = ((c >> 2) & 3) * 16 + (r & 15);
+  return ((tile * 8 + wave) * 8 + blk) * 1024 + ((c >> 5) & 1) * 512 + ((c >> 4) & 1) * 256 + lane * 4 + (c & 3);
+}
+
 // erf-GELU as torch's nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // below fp32 resolution of the surrounding sum and ~5x cheaper than libm erff in a GEMM epilogue).
 __device__ __forceinline__ float erf_as(float x) {

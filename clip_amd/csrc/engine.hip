@@ -86,6 +86,7 @@ struct clip_engine {
   bool fuse_ln = true;
   uint16_t *xres = nullptr;     // tiled (xres_tiled_offset): written and re-read in place by the fused GEMMs
   uint16_t *xres_rm = nullptr;  // row-major: the embedding LayerNorm's copy, residual of the first fused GEMM
+  float* xres32 = nullptr;      // F16R: the FP32 residual stream, tiled (xres32_tiled_offset), rewritten in place
   float* lnpart = nullptr;
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
@@ -236,6 +237,7 @@ int alloc_workspace(clip_engine* e) {
     rc = rc ? rc : dev_alloc(e, (void**)&e->xres, Tp * H * 2);
     rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
   }
+  if (e->res32 && H % 256 == 0) rc = rc ? rc : dev_alloc(e, (void**)&e->xres32, Tp * H * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
   e->ln_tiles = n_tiles;
@@ -245,6 +247,7 @@ int alloc_workspace(clip_engine* e) {
     HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
     HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
   }
+  if (e->xres32) HIP_TRY(hipMemset(e->xres32, 0, Tp * H * 4));
   HIP_TRY(hipMemset(e->lnflags, 0, n_tiles * 4));
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
@@ -345,7 +348,10 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   // producer's pre-LN row, (mean, rstd) and affine (EPI_BIAS_LNRES) — the residual stream never
   // passes through bf16 (tools/rounding_study.py: rounding it was 72 % of the logit error variance).
   // fp32 check mode: the LayerNorm output itself is fp32 and is added directly (EPI_BIAS_RES).
-  const bool fused = !f32 && !e->res32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
+  const bool fused = !f32 && e->fuse_ln && H % 256 == 0 && H / 256 <= 8 && I % 128 == 0;
+  // F16R: fp16 operands with the residual stream in FP32 — fused flow: xres32 (tiled, read and rewritten in place by
+  // the fused GEMMs, first written by the embedding kernel); unfused flow: the fp32 pre-LayerNorm rows as they are
+  const bool res32 = e->res32 && fused;
   int cur = 0;
   const float *g_prev = e->embg, *b_prev = e->embb;
   // fused flow: out = x (bf16) and xres (fp16, tiled, in place: a tile reads exactly the elements it
@@ -353,13 +359,15 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   bool first_res = true;
   // f16 setting: operand copy and residual copy would hold the same fp16 bits, so there is ONE: x, row-major,
   // read as the residual and rewritten in place by the fused GEMMs (no xres / xres_rm traffic at all)
-  constexpr bool single = std::is_same<KS, k_f16>::value;
+  const bool single = std::is_same<KS, k_f16>::value && !res32;
   auto ln_gemm = [&](const void* A, const void* W, const void* W_blk, const float* bias, int M, int K,
                      const float* gamma, const float* beta, bool a_tiled) {
     // (A and W in blocks together: the instantiated form; without a block copy of W, A's consumer reads rows)
     if (a_tiled && W_blk) W = W_blk;
-    GemmArgs a{A, W, bias, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres), e->x, M, H, K,
-               K, K, H, H, EPI_BIAS_LNOUT, false, 2};
+    // (F16R: the fp32 stream starts at the first fused GEMM, whose residual is the embedding's fp16 output x itself)
+    GemmArgs a{A, W, bias, res32 ? (first_res ? (const void*)e->x : (const void*)e->xres32)
+                                 : single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres),
+               e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled; a.w_tiled = a_tiled;
     if (e->epoch == 0xffffffffu) {
       // 2^32 launches on these flags (weeks of continuous scoring): a stale flag could equal a new epoch and let a
@@ -368,8 +376,9 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       if (er != hipSuccess) return er;
       e->epoch = 0;
     }
-    a.lnout = LnOutArgs{single ? nullptr : e->xres, !single && !first_res, e->lnpart, e->lnflags, ++e->epoch,
-                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u};
+    a.lnout = LnOutArgs{res32 ? reinterpret_cast<uint16_t*>(e->xres32) : single ? nullptr : e->xres,
+                        res32 ? !first_res : (!single && !first_res), e->lnpart, e->lnflags, ++e->epoch,
+                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u, res32};
     first_res = false;
     return KS::launch_gemm(a, st);
   };
@@ -385,7 +394,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     HIP_TRY(KS::launch_embed_ln(ids, type_ids, pos_ids, e->word, e->pos, e->type, e->embg, e->embb,
                             c.layer_norm_eps, e->x, T, H, c.vocab_size, c.max_position,
                             c.type_vocab_size, st, f32, (f32 || fused) ? nullptr : e->pre[0],
-                            (f32 || fused) ? nullptr : e->stats[0], fused && !single ? e->xres_rm : nullptr));
+                            (f32 || fused) ? nullptr : e->stats[0], fused && !single && !res32 ? e->xres_rm : nullptr));
   }
   GemmArgs g;
   // bf16: whole 256-row tiles for the persistent GEMM (the workspace is padded); fp32: exact rows
@@ -488,10 +497,12 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);  // residual rows picked by index: no gather pass
       if (fused) {
         // (a one-layer model trims its only layer: the residual is still the embedding's row-major copy)
-        GemmArgs a{e->ctx_rows, L.wo, L.bo, single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres),
+        GemmArgs a{e->ctx_rows, L.wo, L.bo,
+                   res32 && !first_res ? (const void*)e->xres32
+                                       : (single || res32) ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres),
                    e->pre_rows[0], n_seqs, H, H, H, H, H, H, EPI_BIAS_RES16, true};
         a.res_index = focus;
-        a.res_tiles_n = (single || first_res) ? 0 : H / 256;
+        a.res_tiles_n = res32 && !first_res ? -(H / 256) : (single || res32 || first_res) ? 0 : H / 256;
         HIP_TRY(KS::launch_gemm(a, st));
       } else {
         HIP_TRY(res_gemm(e->ctx_rows, L.wo, L.bo, n_seqs, H, e->pre[cur], e->stats[cur], e->pre_rows[0], focus));
@@ -823,7 +834,7 @@ int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens) {
   const clip_config& c = e->cfg;
   *tokens = c.max_tokens;
   const int H = c.hidden_size;
-  if (e->f32 || e->res32 || !e->fuse_ln || H % 256 || H / 256 > 8 || c.intermediate_size % 128) return CLIP_OK;
+  if (e->f32 || !e->fuse_ln || H % 256 || H / 256 > 8 || c.intermediate_size % 128) return CLIP_OK;
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
   // the fused-LayerNorm GEMMs run (CUs / column tiles) row panels of 256 tokens side by side: whole
@@ -950,6 +961,20 @@ int clip_gemm_f16_lnout_inplace(const uint16_t* A, const uint16_t* W, const floa
   if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
   if (!x_inout || !part || !flags || !err || N / 256 > 8 || A == x_inout)
     return fail(CLIP_ERR_ARG, "clip_gemm_f16_lnout_inplace: null buffer, A aliasing x, or more than 8 column tiles");
+  HIP_TRY(k_f16::launch_gemm(g, (hipStream_t)stream));
+  return CLIP_OK;
+}
+
+int clip_gemm_f16_lnout_res32(const uint16_t* A, const uint16_t* W, const float* bias, const float* gamma,
+                              const float* beta, float eps, uint16_t* x_out, float* xres32_inout, float* part,
+                              uint32_t* flags, uint32_t epoch, int32_t* err, int32_t M, int32_t N, int32_t K,
+                              int32_t lda, int32_t ldw, int32_t ldx, void* stream) {
+  GemmArgs g{A, W, bias, xres32_inout, x_out, M, N, K, lda, ldw, ldx, N, EPI_BIAS_LNOUT, false, 2};
+  g.ln_gamma = gamma; g.ln_beta = beta;
+  g.lnout = LnOutArgs{reinterpret_cast<uint16_t*>(xres32_inout), true, part, flags, epoch, eps, err, 0, true};
+  if (const char* msg = gemm_check(g)) return fail(CLIP_ERR_ARG, "%s", msg);
+  if (!x_out || !xres32_inout || !part || !flags || !err || N / 256 > 8)
+    return fail(CLIP_ERR_ARG, "clip_gemm_f16_lnout_res32: null buffer, or more than 8 column tiles");
   HIP_TRY(k_f16::launch_gemm(g, (hipStream_t)stream));
   return CLIP_OK;
 }

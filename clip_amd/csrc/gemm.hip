@@ -247,9 +247,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
           if (EPI == EPI_BIAS_RES16) {
             typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
             const int rr = res_index ? res_index[m] : m;
-            const size_t ro = res_tiles_n > 0 ? xres_tiled_offset(rr, n, res_tiles_n) : (size_t)rr * ldres + n;
-            const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + ro);
-            v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+            if (res_tiles_n < 0) {   // the fp32 residual stream of CLIP_PRECISION_F16R (tiled by the fused GEMMs)
+              const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) +
+                                                                  xres32_tiled_offset(rr, n, -res_tiles_n));
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            } else {
+              const size_t ro = res_tiles_n > 0 ? xres_tiled_offset(rr, n, res_tiles_n) : (size_t)rr * ldres + n;
+              const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + ro);
+              v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+            }
           }
           if (EPI == EPI_BIAS_RES) {
             if constexpr (F32IN) {

@@ -100,7 +100,8 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // same bits); the residual is then read from the row-major buffer this tile rewrites in place (every wave reads
 // exactly the 64 x 64 blocks it writes).
 // LAYOUT bit 0: A, bit 1: the 16-bit output, bit 2: W, stored as contiguous 128 x 64 blocks (GemmArgs::a_tiled /
-// out_tiled / w_tiled)
+// out_tiled / w_tiled); bit 3 (EPI_BIAS_LNOUT with RES_TILED, fp16 operands): the residual read and the residual
+// copy written are FP32, tiled by xres32_tiled_offset (LnOutArgs::res_f32: the residual stream of F16R)
 template <int EPI, bool OUT_F32, bool RES_TILED = false, bool SINGLE = false, int LAYOUT = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
@@ -413,7 +414,45 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       // layer, the row-major copy of the embedding LayerNorm.
       typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
       const size_t xt_base = (((size_t)tm * tiles_n + tn) * 8 + w) * 8192 + lane * 8;  // + blk * 1024 + nh * 512
-      if (RES_TILED) {
+      constexpr bool res32 = (LAYOUT & 8) != 0;
+      if (RES_TILED && res32) {
+        // wave-uniform base + one 32-bit lane offset: the 32 loads share ONE vector register of addressing (scalar
+        // base, immediate offsets) instead of eight 64-bit lane addresses — this kernel has no registers to spare
+        const float* rt_u = reinterpret_cast<const float*>(resv) + (((size_t)tm * tiles_n + tn) * 8 + w) * 8192;
+        const unsigned l4 = lane * 4;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mp = 0; mp < 4; mp += 2) {
+            __builtin_amdgcn_sched_barrier(0);  // 8 loads (32 registers) in flight at a time
+            f32x4_t r[2][2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                  r[k][nh][i] = __builtin_nontemporal_load(
+                      reinterpret_cast<const f32x4_t*>(rt_u + ((mh * 4 + mp + k) * 1024 + nh * 512 + i * 256) + l4));
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    acc[mh][nh][mp + k][i][e] = (acc[mh][nh][mp + k][i][e] + bv[nh][i][e]) + r[k][nh][i][e];
+            // pin the sums here: left alone, the compiler issues the loads of every group first and adds later
+            // (all 32 loads = 128 registers live at once -> ~60 spilled registers, some reloaded inside the K loop)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(acc[mh][nh][mp + k][i]));
+          }
+      } else if (RES_TILED) {
         const uint16_t* rt = reinterpret_cast<const uint16_t*>(resv) + xt_base;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
@@ -583,6 +622,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
       // (1-KiB wave stores), the bf16 GEMM operand through the transpose scratch as whole row segments
       const float* gl = bias_lds + (it & 1) * 768 + 256 + wc * 64 + fq * 4;
       uint16_t* xt = SINGLE ? nullptr : lo.xres_out + xt_base;
+      float* xt32_u = reinterpret_cast<float*>(lo.xres_out) + (((size_t)tm * tiles_n + tn) * 8 + w) * 8192;  // wave-uniform
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -605,8 +645,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(
               const int sl = ((nh * 2 + i) * 4 + fq) ^ ((fr & 7) << 1);
               *reinterpret_cast<uint2*>(scr + fr * 128 + sl * 8) =
                   make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
+              if (res32)   // the residual stream stays fp32: 16 B per lane, 1 KiB per wave store
+                out_store((f32x4_t){y[0], y[1], y[2], y[3]},
+                          reinterpret_cast<f32x4_t*>(xt32_u + ((mh * 4 + m) * 1024 + nh * 512 + i * 256) + (unsigned)(lane * 4)));
             }
-            if (!SINGLE)
+            if (!SINGLE && !res32)
               out_store(*reinterpret_cast<const u32x4_t*>(&hv),
                         reinterpret_cast<u32x4_t*>(xt + (mh * 4 + m) * 1024 + nh * 512));
           }
@@ -788,6 +831,20 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
                          : launch_8<EPI_BIAS_LNOUT, false, false, true>(g, st);
 #else
         return hipErrorInvalidValue;   // bf16 operands need the separate fp16 residual copy
+#endif
+      }
+      if (g.lnout.res_f32) {
+#if CLIP_OPERAND_F16
+        if (g.lnout.res_tiled)
+          return g.a_tiled ? launch_8<EPI_BIAS_LNOUT, false, true, false, 13>(g, st)
+                           : launch_8<EPI_BIAS_LNOUT, false, true, false, 8>(g, st);
+        // where the fp32 stream starts (the first fused GEMM of a forward): the residual is the embedding LayerNorm's
+        // fp16 output, read row-major from the operand buffer this tile rewrites (the SINGLE read path)
+        if (g.res != g.out || g.ldres != g.ldo) return hipErrorInvalidValue;
+        return g.a_tiled ? launch_8<EPI_BIAS_LNOUT, false, false, true, 13>(g, st)
+                         : launch_8<EPI_BIAS_LNOUT, false, false, true, 8>(g, st);
+#else
+        return hipErrorInvalidValue;   // the fp32 residual stream belongs to the fp16 operand set (F16R)
 #endif
       }
       if (g.a_tiled)

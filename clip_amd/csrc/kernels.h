@@ -26,6 +26,8 @@ struct LnOutArgs {         // EPI_BIAS_LNOUT
   int32_t* err;            // |= 2 when a partner tile's statistics did not arrive (bounded spin); sticky:
                            // while bit 1 is set no tile waits for its partners any more
   uint32_t test_drop = 0;  // diagnostic (CLIP_AMD_TEST_DROP_PUBLISH=1): tile 1 never publishes its flag
+  bool res_f32 = false;    // fp16 operand set only (CLIP_PRECISION_F16R): res and xres_out are FP32, tiled by
+                           // xres32_tiled_offset (res_tiled must be set) — the residual stream never leaves fp32
 };
 
 struct GemmArgs {
@@ -44,7 +46,8 @@ struct GemmArgs {
   const float* ln_gamma = nullptr;   // [N]
   const float* ln_beta = nullptr;    // [N]
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
-  int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles
+  int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles;
+                                       // < 0 = res is FP32, tiled by xres32_tiled_offset with -res_tiles_n column tiles
   LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr, 0};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
   // Ping-pong kernel only (engine-internal operands: attention ctx -> attn-out, FFN-up -> FFN-down): the 16-bit
   // matrix is stored as contiguous 128 x 64 blocks, element (r, c) of an [M, C] matrix at

@@ -76,12 +76,13 @@ int clip_finalize_weights(clip_engine* e);
  *     logits NaN (never silently wrong).  BERT-base activations stay far inside it.  In this setting the
  *     LayerNorm output is kept ONCE (fp16, row-major: GEMM operand and residual are the same bits), where
  *     the bf16 setting keeps a bf16 operand copy and an fp16 residual copy;
- *   CLIP_PRECISION_F16R: fp16 operands as above with the RESIDUAL STREAM IN FP32: the N = hidden GEMMs
- *     write fp32 pre-LayerNorm rows, the LayerNorm kernel leaves (mean, rstd), and the next residual add
- *     recomputes the fp32 LayerNorm output in the GEMM epilogue (clip_gemm_bf16_lnres's form on fp16
- *     operands) — the residual never passes through a 16-bit type.  Measured on the trained-like stress
- *     goldens: rms logit error 3.8e-3 -> 2.6e-3, max 2.14e-2 -> 1.97e-2 (inside the 2e-2 budget), at
- *     ~17 % less throughput than CLIP_PRECISION_F16 (more bytes per token; no LayerNorm fusion). */
+ *   CLIP_PRECISION_F16R: fp16 operands as above with the RESIDUAL STREAM IN FP32: the fused-LayerNorm GEMMs
+ *     read and rewrite an fp32 copy of every LayerNorm output (clip_gemm_f16_lnout_res32) beside the fp16
+ *     operand copy — the residual never passes through a 16-bit type.  (Hidden sizes that are not a multiple
+ *     of 256, or clip_set_fused_layernorm(e, 0): fp32 pre-LayerNorm rows + (mean, rstd), the residual
+ *     recomputed in the GEMM epilogue — clip_gemm_bf16_lnres's form on fp16 operands.)  Measured on the
+ *     trained-like stress goldens: rms logit error 3.8e-3 -> 2.6e-3, max 2.14e-2 -> below the 2e-2 budget;
+ *     more bytes per token than CLIP_PRECISION_F16 (7.5 KB instead of 3 KB per fused GEMM). */
 enum { CLIP_PRECISION_BF16 = 0, CLIP_PRECISION_FP32 = 1, CLIP_PRECISION_F16 = 2, CLIP_PRECISION_F16R = 3 };
 int clip_set_precision(clip_engine* e, int32_t precision);
 
@@ -199,6 +200,18 @@ int clip_gemm_f16_lnout_inplace(const uint16_t* dev_A, const uint16_t* dev_W, co
                                 const float* dev_gamma, const float* dev_beta, float eps, uint16_t* dev_x_inout,
                                 float* dev_part, uint32_t* dev_flags, uint32_t epoch, int32_t* dev_err, int32_t M,
                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldx, void* stream);
+/* The F16R setting's form (fp16 operands, FP32 residual stream; same reference math, modeling_bert.py:289-293 /
+ * :347-351): xres32_inout [M, N] fp32 holds the residual on entry and the fp32 LayerNorm output on return — the
+ * residual never passes through a 16-bit type — and x_out (fp16, row stride ldx) receives the same values rounded
+ * once, as the next GEMM's operand.  xres32_inout is TILED in the order of clip_gemm_bf16_lnout's xres_out with the
+ * two 16-column blocks of a lane stored one after the other (16-byte accesses):
+ *   ((tile*8 + wave)*8 + blk)*1024 + nh*512 + i*256 + lane*4 + e      (tile, wave, blk, lane, nh, i, e as above);
+ * a workgroup rewrites exactly the elements it read.  part / flags / epoch / err as clip_gemm_bf16_lnout. */
+int clip_gemm_f16_lnout_res32(const uint16_t* dev_A, const uint16_t* dev_W, const float* dev_bias,
+                              const float* dev_gamma, const float* dev_beta, float eps, uint16_t* dev_x_out,
+                              float* dev_xres32_inout, float* dev_part, uint32_t* dev_flags, uint32_t epoch,
+                              int32_t* dev_err, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                              int32_t ldx, void* stream);
 
 /* clip_gemm_bf16_lnout for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, kernel and

@@ -520,6 +520,60 @@ def test_gemm_f16_fused_layernorm_in_place(lib, M, N, K):
                                                _lib.ptr(err), M, N, K, K, K, N, _lib.stream_ptr()) != 0
 
 
+def _xres32_tiled_index(M, N):
+    """element (row, col) -> offset in the fp32 tiled residual (include/clip_amd.h, clip_gemm_f16_lnout_res32)"""
+    r = torch.arange(M)[:, None].expand(M, N)
+    c = torch.arange(N)[None, :].expand(M, N)
+    tile = (r >> 8) * (N // 256) + (c >> 8)
+    rr, cc = r & 255, c & 255
+    wave = ((rr >> 6) & 1) * 4 + (cc >> 6)
+    blk = (rr >> 7) * 4 + ((rr >> 4) & 3)
+    lane = ((cc >> 2) & 3) * 16 + (rr & 15)
+    return ((tile * 8 + wave) * 8 + blk) * 1024 + ((cc >> 5) & 1) * 512 + ((cc >> 4) & 1) * 256 + lane * 4 + (cc & 3)
+
+
+@pytest.mark.parametrize("M,N,K", [(255 * 256, 768, 768), (36 * 256, 768, 3072), (256, 768, 768), (3 * 256, 1024, 512)])
+def test_gemm_f16_fused_layernorm_fp32_residual(lib, M, N, K):
+    """The F16R setting's fused-LayerNorm GEMM: fp16 operands, the residual read from and the LayerNorm output
+    written back to an FP32 tiled buffer (in place), the fp16 operand copy beside it.  Against an fp64 reference:
+    the fp32 copy to fp32 accuracy of the sum, the fp16 copy = that copy rounded once; same bits on every launch."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 2)
+    A = torch.randn(M, K, generator=g).to(torch.float16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.float16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g) * 1.5 + 0.2                      # fp32 residual rows
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    idx = _xres32_tiled_index(M, N).reshape(-1)
+    assert torch.equal(torch.sort(idx).values, torch.arange(M * N))       # the layout is a permutation
+    tiled = torch.empty(M * N)
+    tiled[idx] = res.reshape(-1)
+    nt = (M // 256) * (N // 256)
+    part = torch.empty(nt * 256 * 2, device="cuda")
+    flags = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    v = A.double() @ W.double().T + bias.double() + res.cuda().double()
+    ref, _, _ = _ln_ref(v, gamma.double(), beta.double())
+    first = None
+    for epoch in range(1, 8):
+        xres = tiled.clone().cuda()
+        x = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        _lib.check(lib.clip_gemm_f16_lnout_res32(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta),
+                                                 1e-12, _lib.ptr(x), _lib.ptr(xres), _lib.ptr(part), _lib.ptr(flags), epoch,
+                                                 _lib.ptr(err), M, N, K, K, K, N, _lib.stream_ptr()))
+        _sync()
+        assert int(err.item()) == 0
+        y32 = xres[idx.cuda()].reshape(M, N)
+        if first is None:
+            assert torch.isfinite(y32).all() and torch.isfinite(x.float()).all()
+            # fp16 operands, fp32 accumulation over K: the fp32 copy carries no 16-bit rounding of its own
+            assert (y32.double() - ref).abs().max().item() < 2e-4 * max(1.0, (K / 768) ** 0.5)
+            assert torch.equal(x, y32.to(torch.float16))                   # the operand copy = the same values rounded once
+            first = (x.clone(), xres.clone())
+        else:
+            assert torch.equal(first[0], x) and torch.equal(first[1], xres), f"launch {epoch} differs"
+
+
 def test_attention_f16_operand_set(lib):
     heads, H = 12, 768
     lens = [1, 7, 64, 65, 128, 129, 200, 256, 300, 512]

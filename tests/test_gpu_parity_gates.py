@@ -176,3 +176,37 @@ def test_f16_setting_on_the_benign_goldens(golden, name):
     err = np.abs(logits - g["ref_logits"]).max()
     print(f"{name}/f16: max |logit - ref| = {err:.3e}")
     assert err < 3e-3          # bf16 on the same goldens: 1.2e-3 .. 7.3e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_ctx", "base_ctx", "base_sent", "base_ctx_stress"])
+def test_f16r_fused_flow_equals_unfused_flow(golden, name):
+    """F16R keeps the residual stream in fp32 in BOTH LayerNorm flows: fused (fp32 tiled copy rewritten in place by
+    clip_gemm_f16_lnout_res32; hidden sizes that are multiples of 256) and unfused (fp32 pre-LayerNorm rows +
+    statistics).  Same logits to within fp16 operand rounding, both inside the budget against the reference; the
+    bulk path and the batches-of-8 path give the same bits in the fused flow."""
+    import os
+    g = golden(name)
+    sd = golden_state_dict(g)
+    out = {}
+    for flow in ("1", "0"):
+        old = os.environ.get("CLIP_AMD_FUSED_LN")
+        os.environ["CLIP_AMD_FUSED_LN"] = flow
+        try:
+            out[flow] = _logits(g["cfg"], sd, g["rows"], g["n_ctx"], "f16r", g["batch_size"])
+            if flow == "1":
+                m = _model(g["cfg"], sd, g["n_ctx"], "f16r")
+                bulk = scoring.BulkScorer(m, keep_logits=True).score(g["rows"]).logits
+                m._drop_engine()
+                assert np.array_equal(bulk, out[flow])
+        finally:
+            if old is None:
+                os.environ.pop("CLIP_AMD_FUSED_LN", None)
+            else:
+                os.environ["CLIP_AMD_FUSED_LN"] = old
+    tol = 2e-2 if name.endswith("stress") else 3e-3
+    for flow, lg in out.items():
+        err = np.abs(lg - g["ref_logits"]).max()
+        print(f"{name}/f16r/fused_ln={flow}: max |logit - ref| = {err:.3e}")
+        assert err < tol
+    # (on the stress golden the two flows carry independent fp16-operand errors of up to ~2e-2 each)
+    assert np.abs(out["1"] - out["0"]).max() < (2.5e-2 if name.endswith("stress") else 2e-3)
