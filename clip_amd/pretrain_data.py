@@ -12,7 +12,8 @@ scoring path wrote to the batches `BertContextMLMSwitch.forward` consumes.  Rest
     sentence (:224-251), switch labels.  The masking draws from torch's global generator with the reference's
     own sequence of calls (bernoulli p, bernoulli 0.8, bernoulli 0.5, randint), so a seeded run produces the
     reference's batches bit for bit (tests/test_pretrain_data.py against goldens from the imported reference).
-  * `select_inputs` (:293-306).
+  * `select_inputs` (:293-306), `evaluate` (:308-331), and the other input form of the same loop: `PrecomputedDataset`
+    (:19-32) + `simple_collate` (:100-134).
 
 Reference quirks kept: `if eval:` (:277) tests the BUILTIN, so 'sentences' is always returned; rows that needed
 back-filled separators are written back AFTER token types and masking were computed from the tokenizer's row
@@ -100,6 +101,55 @@ class SentContextDataset(SentDataset):
                 ctx_sents.append(self.tokenize_sentence(self._sentence[idx + offset]))
         contexts = tuple(" ".join(c) for c in ctx_sents)
         return sent, label, sent_ix, doc_id, contexts                             # :98
+
+
+class PrecomputedDataset:
+    """pretrain_tasks.py:19-32: instances tokenised ahead of time, one JSON object per line with the keys
+    simple_collate reads (input_ids, token_type_ids, mlm_labels, sentences; id lists right-padded with 0)."""
+
+    def __init__(self, fname):
+        import json
+        self.insts = []
+        with open(fname) as f:
+            for line in f:
+                self.insts.append(json.loads(line.strip()))
+
+    def __len__(self):
+        return len(self.insts)
+
+    def __getitem__(self, idx):
+        return self.insts[idx]
+
+
+def get_padded_length(lst, el):
+    """pretrain_tasks.py:100-104: position of the first `el` (the pad id), else the full length"""
+    try:
+        return lst.index(el)
+    except ValueError:
+        return len(lst)
+
+
+def simple_collate(batch):
+    """pretrain_tasks.py:106-134: re-pad precomputed instances to the longest of the batch (token types padded with
+    1, MLM labels with -100), then keep a random 25 % of the candidate MLM positions (one torch.bernoulli draw over
+    the whole [B, S] matrix, as the reference does: a seeded run gives its batches bit for bit)."""
+    batch_len = max(get_padded_length(inst["input_ids"], 0) for inst in batch)
+    input_ids, sentences, attention_mask, token_type_ids, mlm_labels = [], [], [], [], []
+    for inst in batch:
+        n = get_padded_length(inst["input_ids"], 0)
+        input_ids.append(inst["input_ids"][:n] + [0] * (batch_len - n))
+        sentences.append(inst["sentences"])
+        attention_mask.append([1] * n + [0] * (batch_len - n))
+        token_type_ids.append(inst["token_type_ids"][:n] + [1] * (batch_len - n))
+        mlm_labels.append(inst["mlm_labels"][:n] + [-100] * (batch_len - n))
+    mlm_labels = torch.LongTensor(mlm_labels)
+    new_mlm_labels = mlm_labels.clone()
+    prob_mask = torch.zeros(new_mlm_labels.size())
+    prob_mask.masked_fill_(new_mlm_labels != -100, 0.25)
+    new_mask = torch.bernoulli(prob_mask).bool()
+    new_mlm_labels[~new_mask] = -100
+    return {"input_ids": torch.LongTensor(input_ids), "attention_mask": torch.LongTensor(attention_mask),
+            "sentences": sentences, "token_type_ids": torch.LongTensor(token_type_ids), "mlm_labels": new_mlm_labels}
 
 
 def special_ids(tokenizer):

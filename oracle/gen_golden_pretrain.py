@@ -34,6 +34,10 @@ CASES = [   # (n_ctx, switch_prob, same_doc, mlm_probability, seed, batch sizes)
 ]
 
 
+def get_len(ids):
+    return ids.index(0) if 0 in ids else len(ids)
+
+
 def synth_tables():
     rng = np.random.default_rng(99)
     words = [f"w{i:03d}" for i in range(400)] + "patient should follow up with cardiology in 2 weeks".split()
@@ -102,6 +106,29 @@ def main():
                                  "items": [None if it is None else tolist(list(it)) for it in items],
                                  "batches": batches})
             print(focus_name, n_ctx, "items", len(items), "None batches", sum(b is None for b in batches))
+    # PrecomputedDataset + simple_collate (pretrain_tasks.py:19-32, 100-134) over a small JSONL of instances
+    rng = np.random.default_rng(5)
+    insts = []
+    for k in range(9):
+        n, pad = int(rng.integers(6, 40)), int(rng.integers(0, 12))
+        ids = [101] + [int(x) for x in rng.integers(1000, 3000, n)] + [102]
+        cand = [int(t) if rng.random() < 0.5 else -100 for t in ids]
+        insts.append({"input_ids": ids + [0] * pad, "token_type_ids": [0] * len(ids) + [0] * pad,
+                      "mlm_labels": cand + [-100] * pad, "sentences": f"instance {k}"})
+    insts[3]["input_ids"] = insts[3]["input_ids"][:get_len(insts[3]["input_ids"])]      # one without any padding
+    for key in ("token_type_ids", "mlm_labels"):
+        insts[3][key] = insts[3][key][:len(insts[3]["input_ids"])]
+    with open(os.path.join(G, "pretrain_insts.jsonl"), "w") as f:
+        for inst in insts:
+            f.write(json.dumps(inst) + "\n")
+    ds = PT.PrecomputedDataset(os.path.join(G, "pretrain_insts.jsonl"))
+    torch.manual_seed(21)
+    out["precomputed"] = {"seed": 21, "sizes": [4, 3, 2], "batches": []}
+    i = 0
+    for b in out["precomputed"]["sizes"]:
+        r = PT.simple_collate([ds[j] for j in range(i, i + b)])
+        out["precomputed"]["batches"].append({kk: tolist(v) for kk, v in r.items()})
+        i += b
     with gzip.open(os.path.join(G, "pretrain_golden.json.gz"), "wt") as f:
         json.dump(out, f)
     print("wrote", os.path.getsize(os.path.join(G, "pretrain_golden.json.gz")) // 1024, "KB")

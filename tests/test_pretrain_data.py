@@ -70,3 +70,22 @@ def test_select_inputs_keys():
     assert set(PD.select_inputs(batch, "switch", 2)) == {"input_ids", "attention_mask", "labels", "mlm_labels", "token_type_ids"}
     assert set(PD.select_inputs(batch, "mlm", 2)) == {"input_ids", "attention_mask", "mlm_labels", "token_type_ids"}
     assert PD.select_inputs(batch, "mlm", 0)["labels"] == 4
+
+
+def test_precomputed_instances_and_simple_collate_equal_the_reference(gold):
+    ds = PD.PrecomputedDataset(os.path.join(G, "pretrain_insts.jsonl"))
+    pre = gold["precomputed"]
+    assert len(ds) == sum(pre["sizes"])
+    torch.manual_seed(pre["seed"])
+    i = 0
+    kept = cand = 0
+    for b, want in zip(pre["sizes"], pre["batches"]):
+        got = PD.simple_collate([ds[j] for j in range(i, i + b)])
+        cand += sum(sum(1 for t in ds[j]["mlm_labels"] if t != -100) for j in range(i, i + b))
+        i += b
+        assert set(got) == set(want)
+        for key, v in want.items():
+            g = got[key].tolist() if isinstance(got[key], torch.Tensor) else got[key]
+            assert g == v, key
+        kept += int((got["mlm_labels"] != -100).sum())
+    assert 0 < kept < cand          # a subset of the candidate positions survives
