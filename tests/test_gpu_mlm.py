@@ -85,3 +85,28 @@ def test_expand_vocab_by_num(golden):
                              labels=sw.cuda(), mlm_labels=mlm.cuda(), return_mlm_scores=True)
     assert scores.shape[1] == V + 3 and torch.isfinite(scores).all() and torch.isfinite(loss)
     g["cfg"].vocab_size = V                                   # the golden's config object is shared by the session
+
+
+def test_mlm_labels_on_another_device_and_ignored_switch_labels(golden):
+    """mlm_labels may arrive on the CPU while the other tensors are on the GPU, and a switch label of -100 is ignored
+    by the reference's CrossEntropyLoss (bert_model.py:177-183) exactly as an MLM label of -100 is."""
+    import torch.nn.functional as F
+    g = golden("tiny_mlm")
+    m = _model(g, "fp32")
+    ids, mask, tt, sw, mlm, sl = next(batches(g))
+    loss_gpu, logits, scores = m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda(),
+                                 labels=sw.cuda(), mlm_labels=mlm.cuda(), return_mlm_scores=True)
+    loss_cpu_labels, _ = m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda(),
+                           labels=sw, mlm_labels=mlm)                       # labels left on the CPU
+    assert float(loss_cpu_labels) == float(loss_gpu)
+    sw2 = sw.clone()
+    sw2[0] = -100
+    loss_ign, _ = m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda(), labels=sw2.cuda(),
+                    mlm_labels=mlm.cuda())
+    lab = mlm[mlm != -100].cuda()
+    want = F.cross_entropy(scores, lab) + F.cross_entropy(logits, sw2.cuda(), ignore_index=-100)
+    assert torch.isfinite(loss_ign) and abs(float(loss_ign) - float(want)) < 1e-5
+    sw3 = torch.full_like(sw, -100)                                         # no switch label left: torch's mean over zero rows
+    loss_nan, _ = m(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=tt.cuda(), labels=sw3.cuda(),
+                    mlm_labels=mlm.cuda())
+    assert torch.isnan(loss_nan)
