@@ -103,6 +103,7 @@ struct clip_engine {
   hipStream_t last_stream = nullptr;  // stream of the latest forward: clip_poll_errors reads behind it
   bool test_drop = false;             // CLIP_AMD_TEST_DROP_PUBLISH=1 (tests): one fused-LayerNorm tile never publishes
   size_t ln_tiles = 0;                // entries of lnflags
+  bool small_m = true;    // fused-LayerNorm GEMMs of small calls on gemm4.hip's 64 x 256 tiles (CLIP_AMD_SMALL_M=0: off)
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -239,8 +240,9 @@ int alloc_workspace(clip_engine* e) {
   }
   if (e->res32 && H % 256 == 0) rc = rc ? rc : dev_alloc(e, (void**)&e->xres32, Tp * H * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, n_tiles * 4);
-  e->ln_tiles = n_tiles;
+  // (one flag per 64-row tile: 4x what the ping-pong kernel needs; gemm4.hip's small-M form uses them all)
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, 4 * n_tiles * 4);
+  e->ln_tiles = 4 * n_tiles;
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   if (rc) return rc;
   if (two_copies) {
@@ -248,7 +250,7 @@ int alloc_workspace(clip_engine* e) {
     HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
   }
   if (e->xres32) HIP_TRY(hipMemset(e->xres32, 0, Tp * H * 4));
-  HIP_TRY(hipMemset(e->lnflags, 0, n_tiles * 4));
+  HIP_TRY(hipMemset(e->lnflags, 0, 4 * n_tiles * 4));
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
   // persistent GEMM: keep them finite from the start
@@ -363,12 +365,14 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   auto ln_gemm = [&](const void* A, const void* W, const void* W_blk, const float* bias, int M, int K,
                      const float* gamma, const float* beta, bool a_tiled) {
     // (A and W in blocks together: the instantiated form; without a block copy of W, A's consumer reads rows)
+    const void* W_rm = W;
     if (a_tiled && W_blk) W = W_blk;
     // (F16R: the fp32 stream starts at the first fused GEMM, whose residual is the embedding's fp16 output x itself)
     GemmArgs a{A, W, bias, res32 ? (first_res ? (const void*)e->x : (const void*)e->xres32)
                                  : single ? e->x : (first_res ? (const void*)e->xres_rm : (const void*)e->xres),
                e->x, M, H, K, K, K, H, H, EPI_BIAS_LNOUT, false, 2};
     a.ln_gamma = gamma; a.ln_beta = beta; a.a_tiled = a_tiled; a.w_tiled = a_tiled;
+    a.W_rowmajor = W_rm;
     if (e->epoch == 0xffffffffu) {
       // 2^32 launches on these flags (weeks of continuous scoring): a stale flag could equal a new epoch and let a
       // tile run ahead of its partners.  Clear the flags (stream-ordered behind every earlier launch) and start over.
@@ -378,7 +382,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     }
     a.lnout = LnOutArgs{res32 ? reinterpret_cast<uint16_t*>(e->xres32) : single ? nullptr : e->xres,
                         res32 ? !first_res : (!single && !first_res), e->lnpart, e->lnflags, ++e->epoch,
-                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u, res32};
+                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u, res32, e->small_m};
     first_res = false;
     return KS::launch_gemm(a, st);
   };
@@ -630,6 +634,7 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   e->cfg = *c;
   e->device = device_id;
   if (const char* t = getenv("CLIP_AMD_TEST_DROP_PUBLISH")) e->test_drop = t[0] == '1';
+  if (const char* t = getenv("CLIP_AMD_SMALL_M")) e->small_m = t[0] != '0';   // (tests, A/B runs: the ping-pong kernel for every size)
   if (const char* t = getenv("CLIP_AMD_TEST_EPOCH_START")) e->epoch = (uint32_t)strtoul(t, nullptr, 0);  // (tests: epoch wrap)
   *out = e;
   return CLIP_OK;

@@ -821,7 +821,11 @@ hipError_t KSET::launch_gemm8(const GemmArgs& g, hipStream_t st) {
     case EPI_BIAS_RES * 2 + 0: return launch_8<EPI_BIAS_RES, false>(g, st);
     case EPI_BIAS_TANH * 2 + 0: return launch_8<EPI_BIAS_TANH, false>(g, st);
     case EPI_BIAS_LNRES * 2 + 1: return launch_8<EPI_BIAS_LNRES, true>(g, st);
-    case EPI_BIAS_LNOUT * 2 + 0:
+    case EPI_BIAS_LNOUT * 2 + 0: {
+      // few rows: 64 x 256 tiles on 4x the workgroups (gemm4.hip), the same bits
+      const hipError_t e4 = launch_gemm4_lnout(g, st);
+      if (e4 != hipErrorNotReady) return e4;
+    }
       if (g.N / BN > 8 || !g.lnout.part || !g.lnout.flags || !g.lnout.err || !g.res) return hipErrorInvalidValue;
       if (!g.lnout.xres_out) {
 #if CLIP_OPERAND_F16

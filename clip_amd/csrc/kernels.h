@@ -28,6 +28,8 @@ struct LnOutArgs {         // EPI_BIAS_LNOUT
   uint32_t test_drop = 0;  // diagnostic (CLIP_AMD_TEST_DROP_PUBLISH=1): tile 1 never publishes its flag
   bool res_f32 = false;    // fp16 operand set only (CLIP_PRECISION_F16R): res and xres_out are FP32, tiled by
                            // xres32_tiled_offset (res_tiled must be set) — the residual stream never leaves fp32
+  bool small_ok = false;   // `flags` holds (M / 64) * (N / 256) entries (4x the ping-pong kernel's need): calls whose whole
+                           // grid of 64-row tiles is resident at once may run on gemm4.hip's kernel (same bits)
 };
 
 struct GemmArgs {
@@ -56,6 +58,7 @@ struct GemmArgs {
   bool a_tiled = false;    // A is stored that way (lda must equal K)
   bool out_tiled = false;  // the 16-bit output is stored that way (ldo must equal N; EPI_BIAS / EPI_BIAS_GELU)
   bool w_tiled = false;    // W is stored that way (a copy made once when the weights are loaded; ldw must equal K)
+  const void* W_rowmajor = nullptr;   // with w_tiled: the same weight row-major (row stride K), for the small-M kernel
 };
 // ---- launchers that do not depend on the 16-bit operand type (defined once, in the bf16 compile)
 const char* gemm_check(const GemmArgs& g);
@@ -94,6 +97,8 @@ hipError_t launch_mean_loss(const float* row_loss, int n, float* loss, int accum
 #define CLIP_KERNEL_SET_MEMBERS                                                                      \
   static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st);                                  \
   static hipError_t launch_gemm8(const GemmArgs& g, hipStream_t st); /* ping-pong schedule */        \
+  /* EPI_BIAS_LNOUT on 64 x 256 tiles for small M (gemm4.hip); hipErrorNotReady = not its case */   \
+  static hipError_t launch_gemm4_lnout(const GemmArgs& g, hipStream_t st);                           \
   /* varlen self-attention over packed sequences; qkv [T, 3H] (q | k | v, heads of 64), q pre-scaled  \
      by 1/sqrt(64); ctx [T, H].  One workgroup per (128-row q tile, sequence, head). */              \
   static hipError_t launch_attention(const bf16_t* qkv, const int32_t* cu_seqlens, bf16_t* ctx,      \

@@ -210,3 +210,27 @@ def test_f16r_fused_flow_equals_unfused_flow(golden, name):
         assert err < tol
     # (on the stress golden the two flows carry independent fp16-operand errors of up to ~2e-2 each)
     assert np.abs(out["1"] - out["0"]).max() < (2.5e-2 if name.endswith("stress") else 2e-3)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f16r"])
+def test_small_m_fused_gemm_same_bits(precision, monkeypatch):
+    """Calls of a few hundred to a few thousand tokens run their fused-LayerNorm GEMMs on 64 x 256 tiles (gemm4.hip)
+    instead of the ping-pong kernel's 256 x 256: the logits must be the SAME BITS, for the reference's batches of 8
+    (apply_bert_unlabeled.py:92-110), for a mid-sized packed step and against a big step that the ping-pong kernel
+    takes in both runs."""
+    cfg = BertConfig()
+    sd = procedural_state_dict(cfg, 4)
+    flat, off = synth.packed_context_rows(700, 2, cfg.vocab_size, 256, seed=31)
+    rows = scoring.PackedRows(flat, off)
+    small = [rows.flat[rows.offsets[i]:rows.offsets[i + 1]] for i in range(24)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CLIP_AMD_SMALL_M", flag)
+        m = _model(cfg, sd, 2, precision, tokens=131072)
+        big = scoring.BulkScorer(m, keep_logits=True).score(rows).logits                          # one step of ~78 k tokens
+        mid = scoring.BulkScorer(m, keep_logits=True, tokens_per_step=4096).score(rows).logits   # steps of <= 4096 tokens
+        m._drop_engine()
+        out[flag] = (big, mid, _logits(cfg, sd, small, 2, precision, 8))                          # batches of 8 padded rows
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["1"][0], out["1"][1]) and np.array_equal(out["1"][0][:24], out["1"][2])

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../clip_amd/csrc"
 name=$1; shift
 out=../../gpurun_tmp/lib$name.so
 mkdir -p ../../gpurun_tmp/obj_$name
-for f in gemm gemm8 attention rowwise; do       # both operand sets, as the Makefile
+for f in gemm gemm8 gemm4 attention rowwise; do       # both operand sets, as the Makefile
   extra=""; [ $f = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -c $f.hip -o ../../gpurun_tmp/obj_$name/$f.o &
   /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra "$@" -DCLIP_OPERAND_F16=1 -c $f.hip -o ../../gpurun_tmp/obj_$name/${f}_f16.o &
