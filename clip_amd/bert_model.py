@@ -41,10 +41,10 @@ def pack_padded(input_ids, attention_mask=None, token_type_ids=None, position_id
         position_ids = position_ids.expand(B, S)
     pos = position_ids[mask].to(torch.int32).contiguous()
     tt = None if token_type_ids is None else token_type_ids[mask].to(torch.int32).contiguous()
-    lens_h = lens.cpu()
-    if int(lens_h.min()) < 1:
-        raise ValueError("every row needs at least one unmasked token")
-    return ids, tt, pos, cu, int(lens_h.max())
+    # No host read of the lengths (a device sync per call): the padded width S bounds every row (the engine takes
+    # an upper bound for max_seqlen), and a row without any unmasked token is caught on the device (the engine's
+    # row-table check: error word bit 2, raised as ValueError by the poll after the forward).
+    return ids, tt, pos, cu, S
 
 
 class _EngineModel:
@@ -223,7 +223,7 @@ class _EngineModel:
         return h
 
     # ---- the packed fast path (used by clip_amd.scoring) ------------------------------------
-    def focus_index(self, ids, cu_seqlens):
+    def focus_index(self, ids, cu_seqlens, check=True, return_err=False):
         raise NotImplementedError
 
     def forward_packed(self, ids, type_ids, pos_ids, cu_seqlens, max_seqlen, focus=None, check=True):
@@ -232,18 +232,31 @@ class _EngineModel:
         h = self._ensure_engine()
         lib = _lib.load()
         n, T = cu_seqlens.numel() - 1, ids.numel()
+        sep_err = None
         if focus is None:
-            focus = self.focus_index(ids, cu_seqlens, check=check)
+            # the [SEP]-count word is read AFTER the forward has been queued (one wait at the end of the call instead
+            # of one in its middle; a bad row's focus index falls back to the row's first token, in bounds)
+            focus, sep_err = self.focus_index(ids, cu_seqlens, check=False, return_err=True)
         logits = torch.empty((n, self.num_labels), dtype=torch.float32, device=ids.device)
         with torch.cuda.device(self.device):
             _lib.check(lib.clip_forward_packed(h, _lib.ptr(ids), _lib.ptr(type_ids), _lib.ptr(pos_ids),
                                                _lib.ptr(cu_seqlens), _lib.ptr(focus), n, T, int(max_seqlen),
                                                self.head_kind, _lib.ptr(logits), _lib.stream_ptr()))
-            if check:      # 4-byte read behind the forward; the bulk loop (clip_amd.scoring) polls once per chunk
-                _lib.poll_errors(h)
+            if check:      # 4-byte reads behind the forward; the bulk loop (clip_amd.scoring) polls once per chunk
+                _lib.poll_errors(h)       # first: it also CLEARS the engine's word (an empty row sets both)
+                if sep_err is not None:
+                    self._raise_on_sep_count(sep_err)
         return logits
 
-    def _focus(self, ids, cu_seqlens, n_ctx, sep_id, check):
+    def _raise_on_sep_count(self, err):
+        n_ctx = getattr(self, "n_context_sentences", None)
+        if n_ctx is not None and n_ctx >= 0 and int(err.item()) != 0:
+            # reference: prints and returns None, then classifier(None) raises (bert_model.py:51-55,91)
+            print("error when pulling out end of sentence indices: a row does not hold exactly "
+                  f"{2 * n_ctx + 1} [SEP] tokens")
+            raise TypeError("focus-sentence representation is None: wrong [SEP] count in a row")
+
+    def _focus(self, ids, cu_seqlens, n_ctx, sep_id, check, return_err=False):
         lib = _lib.load()
         n = cu_seqlens.numel() - 1
         focus = torch.empty(n, dtype=torch.int32, device=ids.device)
@@ -256,7 +269,7 @@ class _EngineModel:
             print("error when pulling out end of sentence indices: a row does not hold exactly "
                   f"{2 * n_ctx + 1} [SEP] tokens")
             raise TypeError("focus-sentence representation is None: wrong [SEP] count in a row")
-        return focus
+        return (focus, err) if return_err else focus
 
     # ---- the reference's padded forward ------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
@@ -305,10 +318,10 @@ class BertSequenceMultilabelClassificationContext(_EngineModel):
     def set_n_context_sentences(self, n_context_sentences):
         self.n_context_sentences = int(n_context_sentences)
 
-    def focus_index(self, ids, cu_seqlens, check=True):
+    def focus_index(self, ids, cu_seqlens, check=True, return_err=False):
         if self.sep_token_id is None or self.n_context_sentences is None:
             raise AttributeError("call set_sep_token_id() and set_n_context_sentences() first")
-        return self._focus(ids, cu_seqlens, self.n_context_sentences, self.sep_token_id, check)
+        return self._focus(ids, cu_seqlens, self.n_context_sentences, self.sep_token_id, check, return_err)
 
 
 class BertContextMLMSwitch(BertSequenceMultilabelClassificationContext):
@@ -397,8 +410,8 @@ class BertForSequenceMultilabelClassification(_EngineModel):
     """ref: sentclf/bert_model.py:189-251 — BertModel pooler output -> Linear(H, num_labels)."""
     head_kind = 1
 
-    def focus_index(self, ids, cu_seqlens, check=True):
-        return self._focus(ids, cu_seqlens, -1, 0, check)
+    def focus_index(self, ids, cu_seqlens, check=True, return_err=False):
+        return self._focus(ids, cu_seqlens, -1, 0, check, return_err)
 
 
 def args_to_model(n_context_sentences):

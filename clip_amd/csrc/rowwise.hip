@@ -192,8 +192,11 @@ __global__ __launch_bounds__(64) void focus_index_kernel(const int32_t* __restri
   const int s = blockIdx.x;
   const int lane = threadIdx.x;
   const int beg = cu[s], end = cu[s + 1];
+  // an EMPTY row (the row check of the forward rejects it, error word bit 2) still gets an index inside the token
+  // buffer: cu[s] of an empty last row is total_tokens, one row past it
+  const int fallback = beg < end ? beg : (beg > 0 ? beg - 1 : 0);
   if (n_ctx < 0) {  // sentence-only model pools token 0
-    if (lane == 0) focus[s] = beg;
+    if (lane == 0) focus[s] = fallback;
     return;
   }
   int count = 0, found = -1;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(64) void focus_index_kernel(const int32_t* __restri
     count += c;
   }
   if (lane == 0) {
-    focus[s] = found < 0 ? beg : found;
+    focus[s] = found < 0 ? fallback : found;
     if (count != 2 * n_ctx + 1) atomicOr(err, 1);
   }
 }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(64) void prepare_packed_kernel(const int32_t* __res
     count += c;
   }
   if (lane == 0) {
-    focus[s] = (n_ctx > 0 && found >= 0) ? found : beg;
+    focus[s] = (n_ctx > 0 && found >= 0) ? found : (beg < end ? beg : (beg > 0 ? beg - 1 : 0));  // empty row: in bounds
     if (n_ctx > 0 && count != 2 * n_ctx + 1) atomicOr(err, 1);
   }
 }

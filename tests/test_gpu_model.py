@@ -92,6 +92,24 @@ def test_wrong_sep_count_raises_like_the_reference(golden):
               labels=torch.zeros(1, 7, device="cuda"))
 
 
+@pytest.mark.parametrize("name", ["tiny_ctx", "tiny_sent"])
+@pytest.mark.parametrize("empty", [0, 3])
+def test_fully_masked_row_is_rejected(golden, name, empty):
+    """A padded batch with a row of no unmasked token (first or LAST row: its packed offset is total_tokens) is caught
+    by the device-side row check behind the forward — the padded entry point reads no lengths on the host."""
+    g = golden(name)
+    model = build_model(g)
+    ids, mask = O.pad_batch(g["rows"][:4])
+    mask[empty] = 0
+    with pytest.raises(ValueError, match="row table"):
+        model(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=torch.zeros_like(ids).cuda())
+    mask[empty] = (ids[empty] != 0).long()        # the engine's error word was cleared: the next call is clean
+    out = model(input_ids=ids.cuda(), attention_mask=mask.cuda(),
+                token_type_ids=O.token_type_ids_from_seps(ids, 102, g["n_ctx"]).cuda() if g["n_ctx"] > 0 else None)[0]
+    assert torch.isfinite(out).all()
+    assert np.abs(out.cpu().numpy() - g["ref_logits"][:4]).max() < BF16_LOGIT_TOL
+
+
 def test_no_cpu_path(golden):
     g = golden("tiny_ctx")
     model = args_to_model(2)(g["cfg"])
