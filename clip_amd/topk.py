@@ -47,11 +47,12 @@ def merge_topk(record_lists, k):
     return rec[o]
 
 
-def global_topk(local_records, k, group=None, device=None):
+def global_topk(local_records, k, group=None, device=None, always_collective=False):
     """All-gather every rank's local top-k (padded to k records) and merge; identical on all ranks.
-    Without an initialised process group this is the single-rank identity."""
+    Without an initialised process group this is the single-rank identity; so is a group of ONE rank unless
+    `always_collective` (the one-GPU rehearsal of the RCCL leg: tests/test_gpu_multirank.py)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always_collective):
         return merge_topk([local_records], k)
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)

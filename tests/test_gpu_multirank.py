@@ -85,3 +85,19 @@ def test_cli_two_ranks_files_identical_to_one_rank(tmp_path):
         outs[-1] += tuple(np.load(run / "rows" / f"{k}.npy").tobytes() for k in ("flat", "offsets", "doc_ids", "sent_ixs"))
     assert outs[0] == outs[1]
     assert outs[0][0].count(b"\n") == 33 and outs[0][1].count(b"\n") == 26     # 33 rows in >= 4 chunks of whole documents
+
+
+def test_rccl_group_and_fused_flow_in_one_process():
+    """One card allows one RCCL rank: the "nccl" process group (size 1), the job's collectives on device memory and the
+    production kernel flow (fused-LayerNorm GEMMs ON — the two-rank rehearsals above share a card and must switch them
+    off) in the same process.  The N >= 2 RCCL runs themselves are the driver's, on a whole node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CLIP_AMD_FUSED_LN")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    p = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tests", "rccl_one_rank_child.py")], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["world"] == 1 and line["fused_layernorm"] is True
+    assert line["gather_equals_local_merge"] is True and line["records"] > 0
+    assert line["totals"] == line["expected_totals"]
+    assert line["same_bits_after_collectives"] is True and line["finite"] is True
