@@ -39,6 +39,7 @@ SIGNATURES = {
     "clip_focus_index": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
     "clip_prepare_packed": [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
+    "clip_forward_padded": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
     "clip_mlm_head": [_p, _p, _p, _i32, _p, _p, _i32, _p],
@@ -89,7 +90,7 @@ def load():
     return lib
 
 
-ERR_LN_TIMEOUT, ERR_ROW_TABLE, ERR_NONFINITE = 2, 4, 8     # bits of the device error word (clip_poll_errors)
+ERR_SEP_COUNT, ERR_LN_TIMEOUT, ERR_ROW_TABLE, ERR_NONFINITE = 1, 2, 4, 8     # bits of the device error word (clip_poll_errors)
 
 
 def poll_errors(engine):
@@ -102,6 +103,11 @@ def poll_errors(engine):
     if flags.value & ERR_ROW_TABLE:
         raise ValueError(f"engine error word {flags.value}: inconsistent row table (a row longer than max_seqlen, "
                          "an empty row, or cu_seqlens not ending at total_tokens); results of the call are void")
+    if flags.value & ERR_SEP_COUNT:
+        # reference: prints and returns None, then classifier(None) raises (bert_model.py:51-55,91)
+        print("error when pulling out end of sentence indices: a row does not hold exactly 2 * n_context_sentences + 1 "
+              "[SEP] tokens")
+        raise TypeError("focus-sentence representation is None: wrong [SEP] count in a row")
     if flags.value & ERR_NONFINITE:
         raise FloatingPointError(f"engine error word {flags.value}: non-finite logits (an activation left the operand "
                                  "type's range — fp16 tops out at 65504: use precision 'bf16' or 'fp32' for this "

@@ -23,28 +23,10 @@ from .weights import state_dict_shapes
 _IGNORED_KEYS = ("bert.embeddings.position_ids", "bert.embeddings.token_type_ids")
 
 
-def pack_padded(input_ids, attention_mask=None, token_type_ids=None, position_ids=None):
-    """[B,S] padded tensors -> packed int32 (ids, type_ids, pos_ids, cu_seqlens, max_len).
-    Tokens with attention_mask == 1 are kept, in row-major order; the reference's key-padding mask
-    (transformers modeling_bert.py:688-708) becomes the packing."""
-    B, S = input_ids.shape
-    dev = input_ids.device
-    mask = torch.ones((B, S), dtype=torch.bool, device=dev) if attention_mask is None \
-        else attention_mask.to(torch.bool)
-    lens = mask.sum(1, dtype=torch.int32)
-    cu = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    cu[1:] = torch.cumsum(lens, 0)
-    ids = input_ids[mask].to(torch.int32).contiguous()
-    if position_ids is None:
-        position_ids = torch.arange(S, device=dev).unsqueeze(0).expand(B, S)
-    else:
-        position_ids = position_ids.expand(B, S)
-    pos = position_ids[mask].to(torch.int32).contiguous()
-    tt = None if token_type_ids is None else token_type_ids[mask].to(torch.int32).contiguous()
-    # No host read of the lengths (a device sync per call): the padded width S bounds every row (the engine takes
-    # an upper bound for max_seqlen), and a row without any unmasked token is caught on the device (the engine's
-    # row-table check: error word bit 2, raised as ValueError by the poll after the forward).
-    return ids, tt, pos, cu, S
+def _dev_i64(t, device):
+    """a [B, S]-shaped argument of the padded call as contiguous int64 on the model's device (no-op for the tensors the
+    HF tokenizer / the collators produce), None kept"""
+    return None if t is None else t.to(device=device, dtype=torch.int64).contiguous()
 
 
 class _EngineModel:
@@ -281,13 +263,35 @@ class _EngineModel:
             raise NotImplementedError("doc_position feature is not on the scoring path")
         if input_ids.device != self.device:
             raise RuntimeError(f"inputs on {input_ids.device}, model on {self.device}")
-        ids, tt, pos, cu, max_len = pack_padded(input_ids, attention_mask, token_type_ids, position_ids)
-        B = input_ids.shape[0]
-        if ids.numel() > self.max_tokens or B > self.max_seqs:
-            raise _lib.ClipError(_lib.CLIP_ERR_CAPACITY,
-                                 f"batch of {B} rows / {ids.numel()} tokens exceeds the engine workspace "
-                                 f"({self.max_seqs} / {self.max_tokens}); construct with larger max_tokens/max_seqs")
-        logits = self.forward_packed(ids, tt, pos, cu, max_len)
+        if input_ids.dim() != 2:
+            raise ValueError(f"input_ids must be [batch, width], got {tuple(input_ids.shape)}")
+        B, S = input_ids.shape
+        ids = _dev_i64(input_ids, self.device)
+        mask = _dev_i64(attention_mask, self.device)
+        tt = _dev_i64(token_type_ids, self.device)
+        pos, pos_stride = None, 0
+        if position_ids is not None:           # [S], [1, S] (broadcast, modeling_bert.py:83) or [B, S]
+            pos = _dev_i64(position_ids, self.device).reshape(-1, S)
+            if pos.shape[0] not in (1, B):
+                raise ValueError(f"position_ids of shape {tuple(position_ids.shape)} for a batch of {B} x {S}")
+            pos_stride = S if pos.shape[0] == B and B > 1 else 0
+        for name, t in (("attention_mask", mask), ("token_type_ids", tt)):
+            if t is not None and tuple(t.shape) != (B, S):
+                raise ValueError(f"{name} of shape {tuple(t.shape)} for input_ids of shape {(B, S)}")
+        h = self._ensure_engine()
+        logits = torch.empty((B, self.num_labels), dtype=torch.float32, device=self.device)
+        n_ctx = getattr(self, "n_context_sentences", None)
+        if self.head_kind == 0 and (getattr(self, "sep_token_id", None) is None or n_ctx is None):
+            raise AttributeError("call set_sep_token_id() and set_n_context_sentences() first")
+        with torch.cuda.device(self.device):
+            # ONE call: packs the rows on the device (the key-padding mask becomes the packing), finds the focus [SEP],
+            # runs the encoder; one wait inside (the token count), one here (the engine's error word: an empty row, a
+            # wrong [SEP] count, non-finite logits)
+            _lib.check(_lib.load().clip_forward_padded(
+                h, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(tt), _lib.ptr(pos), pos_stride, B, S,
+                int(getattr(self, "sep_token_id", None) or 0), int(n_ctx if n_ctx is not None else -1), self.head_kind,
+                _lib.ptr(logits), None, _lib.stream_ptr()))
+            _lib.poll_errors(h)
         if labels is None:
             return (logits,)
         if self.task != "multilabel":

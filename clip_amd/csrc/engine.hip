@@ -90,6 +90,8 @@ struct clip_engine {
   float* lnpart = nullptr;
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
+  // packed rows of clip_forward_padded: ids / type ids / position ids [max_tokens], cu [max_seqs + 1], focus [max_seqs]
+  int32_t *pk_ids = nullptr, *pk_tt = nullptr, *pk_pos = nullptr, *pk_cu = nullptr, *pk_focus = nullptr;
   uint32_t epoch = 0;
   // LM prediction head of BertContextMLMSwitch (bert_model.py:113,165; optional weights mlm_predictions.*)
   void *w_mlm_t = nullptr, *w_mlm_dec = nullptr;  // transform dense [H,H]; decoder [vocab_pad,H] (zero rows past vocab)
@@ -244,6 +246,11 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, 4 * n_tiles * 4);
   e->ln_tiles = 4 * n_tiles;
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pk_ids, (size_t)c->max_tokens * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pk_tt, (size_t)c->max_tokens * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pk_pos, (size_t)c->max_tokens * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pk_cu, ((size_t)c->max_seqs + 1) * 4);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->pk_focus, (size_t)c->max_seqs * 4);
   if (rc) return rc;
   if (two_copies) {
     HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
@@ -615,7 +622,7 @@ int mlm_head_impl(clip_engine* e, const int32_t* rows, const int32_t* labels, in
 extern "C" {
 
 const char* clip_last_error(void) { return g_err.c_str(); }
-int clip_abi_version(void) { return 2; }
+int clip_abi_version(void) { return 3; }
 
 int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   if (!c || !out) return fail(CLIP_ERR_ARG, "clip_create: null argument");
@@ -811,6 +818,41 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   if (e && e->f16)
     return forward_packed_impl<k_f16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
   return forward_packed_impl<k_bf16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
+}
+
+int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t* attention_mask,
+                        const int64_t* token_type_ids, const int64_t* position_ids, int64_t position_row_stride,
+                        int32_t B, int32_t S, int32_t sep_id, int32_t n_ctx, int32_t head_kind, float* logits,
+                        int32_t* total_tokens, void* stream) {
+  if (!e || !input_ids || !logits) return fail(CLIP_ERR_ARG, "clip_forward_padded: null argument");
+  if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_padded: weights not finalized");
+  if (total_tokens) *total_tokens = 0;
+  if (B == 0) return CLIP_OK;
+  if (B < 0 || S < 1 || position_row_stride < 0)
+    return fail(CLIP_ERR_ARG, "clip_forward_padded: bad sizes (batch %d, width %d)", B, S);
+  if (B > e->cfg.max_seqs)
+    return fail(CLIP_ERR_CAPACITY, "clip_forward_padded: batch of %d rows exceeds the engine workspace (%d rows)", B,
+                e->cfg.max_seqs);
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  // lengths and row offsets first: the launch geometry of everything after needs the token count on the host
+  // (the one wait of this entry point, behind two tiny kernels)
+  HIP_TRY(launch_pack_lengths(attention_mask, B, S, e->pk_cu, st));
+  int32_t T = 0;
+  HIP_TRY(hipMemcpyAsync(&T, e->pk_cu + B, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (total_tokens) *total_tokens = T;
+  if (T > e->cfg.max_tokens)
+    return fail(CLIP_ERR_CAPACITY, "clip_forward_padded: batch of %d rows / %d tokens exceeds the engine workspace (%d / %d)",
+                B, T, e->cfg.max_seqs, e->cfg.max_tokens);
+  if (T < 1) return fail(CLIP_ERR_ARG, "clip_forward_padded: no unmasked token in the batch");
+  HIP_TRY(launch_pack_tokens(input_ids, attention_mask, token_type_ids, position_ids, (long)position_row_stride, B, S,
+                             e->pk_cu, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, st));
+  // wrong [SEP] count (bert_model.py:51-55): bit 0 of the ENGINE's error word, read by the same poll as the rest
+  HIP_TRY(launch_focus_index(e->pk_ids, e->pk_cu, B, sep_id, head_kind == 1 ? -1 : n_ctx, e->pk_focus, e->dev_err, st));
+  const int max_seqlen = S < e->cfg.max_position ? S : e->cfg.max_position;   // a longer row: error word bit 2
+  return clip_forward_packed(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu, e->pk_focus, B, T,
+                             max_seqlen, head_kind, logits, stream);
 }
 
 int clip_mlm_head(clip_engine* e, const int32_t* rows, const int32_t* labels, int32_t n, float* scores_out,

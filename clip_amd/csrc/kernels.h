@@ -133,6 +133,11 @@ struct k_f16 { CLIP_KERNEL_SET_MEMBERS };
 // err |= 4 unless cu_seqlens[0] == 0, every row has 1..max_seqlen tokens and cu_seqlens[n] == total_tokens
 hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
                              int32_t* err, hipStream_t st);
+// padded [B, S] int64 tensors -> packed rows (rowwise.hip): lengths + prefix sums into cu[0..B], then the compaction
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, hipStream_t st);
+hipError_t launch_pack_tokens(const int64_t* ids, const int64_t* mask, const int64_t* tt, const int64_t* pos,
+                              long pos_row_stride, int B, int S, const int32_t* cu, int32_t* out_ids,
+                              int32_t* out_tt, int32_t* out_pos, hipStream_t st);
 // logits[0..count) = NaN when *err != 0
 hipError_t launch_poison_logits(int32_t* err, float* logits, int count, hipStream_t st);
 

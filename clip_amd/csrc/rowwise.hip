@@ -321,6 +321,92 @@ __global__ __launch_bounds__(256) void check_rows_kernel(const int32_t* __restri
   if (bad) atomicOr(err, 4);
 }
 
+// ---- the reference's PADDED call shape (model(**inputs): apply_bert_unlabeled.py:110, test_load.py:36) ----
+// [B, S] int64 tensors as the HF tokenizer / the collators hand them over (sentclf/bert.py:57,152) -> the packed
+// int32 arrays of clip_forward_packed, on the device: tokens with attention_mask != 0 are kept in row-major order
+// (the key-padding mask of modeling_bert.py:688-708 becomes the packing).  Three small kernels instead of the
+// boolean-mask indexing of a tensor library (three device-to-host waits per call there).
+// One wave per row: cu[b + 1] <- number of kept tokens of row b (no mask: S).
+__global__ __launch_bounds__(256) void pack_lens_kernel(const int64_t* __restrict__ mask, int B, int S,
+                                                        int32_t* __restrict__ cu) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int n = S;
+  if (mask) {
+    n = 0;
+    for (int j0 = 0; j0 < S; j0 += 64) {
+      const int j = j0 + lane;
+      n += __popcll(__ballot(j < S && mask[(size_t)b * S + j] != 0));
+    }
+  }
+  if (lane == 0) cu[b + 1] = n;
+}
+
+// cu[0] = 0, cu[1..B] <- inclusive prefix sums of the lengths pack_lens_kernel left there; ONE workgroup.
+__global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ cu, int B) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) { cu[0] = 0; carry = 0; }
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int i = base + tid;
+    int x = i < B ? cu[i + 1] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    if (w == 0) {
+      int t = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int y = __shfl_up(t, o);
+        if (lane >= o) t += y;
+      }
+      if (lane < 16) wsum[lane] = t;
+    }
+    __syncthreads();
+    const int total = carry + (w > 0 ? wsum[w - 1] : 0) + x;
+    if (i < B) cu[i + 1] = total;
+    __syncthreads();
+    if (tid == 1023) carry = total;
+    __syncthreads();
+  }
+}
+
+// One wave per row: stable compaction of the kept tokens to [cu[b], cu[b + 1]).  position ids: the caller's
+// (row stride 0 = one row broadcast, modeling_bert.py:83), else the PADDED column index (transformers' default
+// arange(S): a hole in the mask does not renumber what follows).
+__global__ __launch_bounds__(256) void pack_tokens_kernel(const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ mask,
+                                                          const int64_t* __restrict__ tt,
+                                                          const int64_t* __restrict__ pos, long pos_row_stride,
+                                                          int B, int S, const int32_t* __restrict__ cu,
+                                                          int32_t* __restrict__ out_ids,
+                                                          int32_t* __restrict__ out_tt,
+                                                          int32_t* __restrict__ out_pos) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int dst0 = cu[b], end = cu[b + 1];
+  int count = 0;
+  for (int j0 = 0; j0 < S; j0 += 64) {
+    const int j = j0 + lane;
+    const size_t at = (size_t)b * S + j;
+    const bool keep = j < S && (!mask || mask[at] != 0);
+    const unsigned long long m = __ballot(keep);
+    const int d = dst0 + count + __popcll(m & ((1ull << lane) - 1));
+    if (keep && d < end) {   // d < end always (same mask as pack_lens_kernel); the guard bounds a racing caller
+      out_ids[d] = (int32_t)ids[at];
+      if (out_tt) out_tt[d] = tt ? (int32_t)tt[at] : 0;
+      out_pos[d] = pos ? (int32_t)pos[(size_t)b * pos_row_stride + j] : j;
+    }
+    count += __popcll(m);
+  }
+}
+
 // Last kernel of a forward: a non-zero device error word (fused-LayerNorm exchange timed out, bad row
 // table) turns every logit of the call into NaN, so that a void result cannot be mistaken for scores
 // even by a caller that never polls clip_poll_errors.
@@ -506,6 +592,22 @@ hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_to
   if (n_seqs <= 0) return hipSuccess;
   hipLaunchKernelGGL(check_rows_kernel, dim3((n_seqs + 255) / 256), dim3(256), 0, st, cu_seqlens, n_seqs,
                      total_tokens, max_seqlen, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, S, cu);
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cu, B);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_tokens(const int64_t* ids, const int64_t* mask, const int64_t* tt, const int64_t* pos,
+                              long pos_row_stride, int B, int S, const int32_t* cu, int32_t* out_ids,
+                              int32_t* out_tt, int32_t* out_pos, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, mask, tt, pos, pos_row_stride,
+                     B, S, cu, out_ids, out_tt, out_pos);
   return hipGetLastError();
 }
 

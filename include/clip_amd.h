@@ -114,6 +114,22 @@ int clip_forward_packed(clip_engine* e, const int32_t* dev_ids, const int32_t* d
                         const int32_t* dev_focus, int32_t n_seqs, int32_t total_tokens,
                         int32_t max_seqlen, int32_t head_kind, float* dev_logits, void* stream);
 
+/* Replaces model(**inputs) on the reference's own PADDED tensors (apply_bert_unlabeled.py:110;
+ * test_load.py:36; bert_model.py:66-103): int64 [B, S] row-major device arrays as the HF tokenizer
+ * and the collators produce them (sentclf/bert.py:57,152).  attention_mask (NULL = all ones) selects
+ * the tokens (modeling_bert.py:688-708); token_type_ids may be NULL (all zero); position_ids may be
+ * NULL (the padded column index, modeling_bert.py:65,83), else `position_row_stride` is 0 for one
+ * broadcast row or S for B rows.  The engine packs the rows on the device into its own workspace
+ * (one wait for the token count, returned in *total_tokens when not NULL), finds the focus index
+ * (sep_id, n_ctx as clip_focus_index; ignored for head_kind 1) and runs clip_forward_packed.  A row
+ * with a wrong [SEP] count sets bit 0 of the engine's error word, a row without any unmasked token
+ * (or longer than max_position) bit 2: poll with clip_poll_errors. */
+int clip_forward_padded(clip_engine* e, const int64_t* dev_input_ids, const int64_t* dev_attention_mask,
+                        const int64_t* dev_token_type_ids, const int64_t* dev_position_ids,
+                        int64_t position_row_stride, int32_t batch, int32_t width, int32_t sep_id,
+                        int32_t n_ctx, int32_t head_kind, float* dev_logits, int32_t* total_tokens,
+                        void* stream);
+
 /* Replaces the numpy epilogue of the driver (apply_bert_unlabeled.py:111-124) and the per-label
  * decision of test_load.py:37-38: probs = sigmoid(logits) (fp32); labels[i,j] = (double)p > t_j
  * (strict, fp64 thresholds); keep[i] = any_j(p > any_thresh) (fp32 compare, as numpy does for a
@@ -277,6 +293,8 @@ int clip_set_fused_layernorm(clip_engine* e, int32_t on);
 int clip_preferred_step_tokens(clip_engine* e, int32_t* tokens);
 /* Device-side error word of the engine since the last poll (read behind the latest forward on that
  * forward's stream, then cleared):
+ *   bit 0 (1) = clip_forward_padded only: a row did not hold exactly 2*n_ctx+1 separators (the reference
+ *               prints and fails in its classifier: bert_model.py:51-55,91);
  *   bit 1 (2) = a fused-LayerNorm tile's partner statistics did not arrive within the spin bound (a GPU
  *               shared with work that kept a workgroup from being scheduled; the fused flow needs its
  *               3 column-tile workgroups co-resident).  Sticky on the device: while it is set no later

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.clip_abi_version() == 2
+    assert lib.clip_abi_version() == 3
 
 
 def test_argument_errors_without_a_device():

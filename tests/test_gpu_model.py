@@ -110,6 +110,61 @@ def test_fully_masked_row_is_rejected(golden, name, empty):
     assert np.abs(out.cpu().numpy() - g["ref_logits"][:4]).max() < BF16_LOGIT_TOL
 
 
+def _packed_by_indexing(model, ids, mask, tt, pos):
+    """the padded call restated with boolean-mask indexing, through the packed entry point"""
+    m = mask.bool()
+    lens = m.sum(1)
+    cu = torch.zeros(ids.shape[0] + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    return model.forward_packed(ids[m].int().cuda(), tt[m].int().cuda(), pos.expand_as(ids)[m].int().cuda(), cu.cuda(),
+                                int(ids.shape[1]))
+
+
+def test_padded_call_packs_on_the_device_like_boolean_indexing(golden):
+    """clip_forward_padded's three pack kernels against torch's `tensor[mask]`: right-padded rows, HOLES in the mask
+    (a dropped token does not renumber the default positions after it), caller's position ids per row and as one
+    broadcast row, no mask at all."""
+    g = golden("tiny_ctx")
+    model = build_model(g)
+    ids, mask = O.pad_batch(g["rows"][:6])
+    B, S = ids.shape
+    tt = O.token_type_ids_from_seps(ids, 102, g["n_ctx"])
+    col = torch.arange(S).unsqueeze(0)
+    holes = mask.clone()
+    for b in (1, 4):
+        j = next(j for j in range(1, S) if ids[b, j] not in (0, 101, 102))
+        holes[b, j] = 0
+    gen = torch.Generator().manual_seed(3)
+    rand_pos = torch.randint(0, g["cfg"].max_position_embeddings, (B, S), generator=gen)
+    cases = [("right-padded", mask, None, col), ("holes", holes, None, col), ("positions per row", mask, rand_pos, rand_pos),
+             ("one broadcast row", holes, rand_pos[:1], rand_pos[:1]), ("1-d positions", mask, rand_pos[0], rand_pos[:1])]
+    for name, mk, pos_arg, pos_ref in cases:
+        out = model(input_ids=ids.cuda(), attention_mask=mk.cuda(), token_type_ids=tt.cuda(),
+                    position_ids=None if pos_arg is None else pos_arg.cuda())[0]
+        assert torch.equal(out, _packed_by_indexing(model, ids, mk, tt, pos_ref)), name
+    full = ids.clone()
+    full[full == 0] = 7                      # no mask: every column is a token
+    out = model(input_ids=full.cuda(), token_type_ids=tt.cuda())[0]
+    assert torch.equal(out, _packed_by_indexing(model, full, torch.ones_like(full), tt, col))
+    out = model(input_ids=ids.int().cuda(), attention_mask=mask.bool().cuda(), token_type_ids=tt.int().cuda())[0]   # other dtypes
+    assert torch.equal(out, _packed_by_indexing(model, ids, mask, tt, col))
+
+
+def test_padded_call_with_more_rows_than_one_scan_block(golden):
+    """2 500 rows: the prefix sum of the row lengths takes three rounds of its 1 024-thread workgroup."""
+    g = golden("tiny_sent")
+    model = args_to_model(0)(g["cfg"], max_tokens=131072, max_seqs=4096)
+    from conftest import golden_state_dict
+    model.load_state_dict(golden_state_dict(g))
+    model.to("cuda").eval()
+    model.set_task("multilabel")
+    rows = [g["rows"][i % len(g["rows"])][:1 + (i * 7) % 23] for i in range(2500)]
+    ids, mask = O.pad_batch(rows)
+    out = model(input_ids=ids.cuda(), attention_mask=mask.cuda())[0]
+    ref = _packed_by_indexing(model, ids, mask, torch.zeros_like(ids), torch.arange(ids.shape[1]).unsqueeze(0))
+    assert torch.equal(out, ref)
+
+
 def test_no_cpu_path(golden):
     g = golden("tiny_ctx")
     model = args_to_model(2)(g["cfg"])
