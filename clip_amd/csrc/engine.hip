@@ -105,7 +105,7 @@ struct clip_engine {
   hipStream_t last_stream = nullptr;  // stream of the latest forward: clip_poll_errors reads behind it
   bool test_drop = false;             // CLIP_AMD_TEST_DROP_PUBLISH=1 (tests): one fused-LayerNorm tile never publishes
   size_t ln_tiles = 0;                // entries of lnflags
-  bool small_m = true;    // fused-LayerNorm GEMMs of small calls on gemm4.hip's 64 x 256 tiles (CLIP_AMD_SMALL_M=0: off)
+  int small_m = 2;        // fused-LayerNorm GEMMs of small calls on gemm4.hip's tiles (CLIP_AMD_SMALL_M: 0 off, 1 64 x 256 only, 2 also 64 x 64)
   bool trim_last = true;  // last layer: only the pooled row of each sequence past the K/V projection
   // HIP-event profiling of kernel kinds inside clip_forward_packed (clip_profile_*)
   uint32_t prof_mask = 0;
@@ -241,10 +241,10 @@ int alloc_workspace(clip_engine* e) {
     rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
   }
   if (e->res32 && H % 256 == 0) rc = rc ? rc : dev_alloc(e, (void**)&e->xres32, Tp * H * 4);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, 4 * n_tiles * 256 * 8);   // per 64-column chunk (gemm4.hip's 64 x 64 form)
   // (one flag per 64-row tile: 4x what the ping-pong kernel needs; gemm4.hip's small-M form uses them all)
-  rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, 4 * n_tiles * 4);
-  e->ln_tiles = 4 * n_tiles;
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, 16 * n_tiles * 4);      // per 64 x 64 tile
+  e->ln_tiles = 16 * n_tiles;
   rc = rc ? rc : dev_alloc(e, (void**)&e->dev_err, 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->pk_ids, (size_t)c->max_tokens * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->pk_tt, (size_t)c->max_tokens * 4);
@@ -257,7 +257,7 @@ int alloc_workspace(clip_engine* e) {
     HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
   }
   if (e->xres32) HIP_TRY(hipMemset(e->xres32, 0, Tp * H * 4));
-  HIP_TRY(hipMemset(e->lnflags, 0, 4 * n_tiles * 4));
+  HIP_TRY(hipMemset(e->lnflags, 0, 16 * n_tiles * 4));
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
   // persistent GEMM: keep them finite from the start
@@ -641,7 +641,7 @@ int clip_create(const clip_config* c, int device_id, clip_engine** out) {
   e->cfg = *c;
   e->device = device_id;
   if (const char* t = getenv("CLIP_AMD_TEST_DROP_PUBLISH")) e->test_drop = t[0] == '1';
-  if (const char* t = getenv("CLIP_AMD_SMALL_M")) e->small_m = t[0] != '0';   // (tests, A/B runs: the ping-pong kernel for every size)
+  if (const char* t = getenv("CLIP_AMD_SMALL_M")) e->small_m = t[0] == '0' ? 0 : t[0] == '1' ? 1 : 2;   // (tests, A/B runs: the ping-pong kernel for every size)
   if (const char* t = getenv("CLIP_AMD_TEST_EPOCH_START")) e->epoch = (uint32_t)strtoul(t, nullptr, 0);  // (tests: epoch wrap)
   *out = e;
   return CLIP_OK;

@@ -281,10 +281,246 @@ __global__ __launch_bounds__(512) void gemm4_lnout_kernel(
   }
 }
 
+
+// ---- 64 x 64 tiles: the same GEMM for calls of at most a few hundred rows more (one batch of the reference's loop) ----
+// A workgroup (4 waves, one 16-row block each) owns 64 rows x ONE 64-column chunk — the unit whose row sums the other two
+// kernels form inside a wave — so a batch of 8 sentences spreads over (M / 64) * (N / 64) = 192 workgroups instead of 48,
+// each pulling 16 KiB per K tile through an 8-stage LDS-DMA ring (7 tiles in flight).  The sums of the four chunks of a
+// 256-column group, which the other kernels add across waves in LDS, are added here after the exchange, in the same
+// order: ((c0 + c1) + (c2 + c3)), then the groups in index order — the SAME BITS again.
+// blockIdx -> (panel, chunk): workgroup b runs on XCD b % 8; an XCD takes a quarter of the panels x half of the chunks,
+// so its L2 holds (P / 4) A panels and (C / 2) weight chunks instead of a bit of everything.
+constexpr int QM = 64, QN = 64;
+constexpr int QSTAGE = QM * 128 + QN * 128;           // 16 KiB
+constexpr int QNST = 8, QD = QNST - 1;
+constexpr int LDSQ = QNST * QSTAGE + 2 * 512;         // + (mean, rstd) per row, + spare
+
+#define VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * n) : "memory"); break;
+
+__global__ __launch_bounds__(256) void gemm4n_lnout_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    const void* resv, void* out, int K, int lda, int ldw, int ldo, int ldres, int tiles_n, int a_tiled,
+    const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, LnOutArgs lo, int res_mode, int out_mode,
+    int panels) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // 16-row block of the panel
+  const int chunks_n = tiles_n * 4;
+  int panel, chunk;
+  {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pq = panels >> 2, ch = chunks_n >> 1;              // panels per XCD row, chunks per XCD column
+    panel = (xcd >> 1) * pq + j / ch;
+    chunk = (xcd & 1) * ch + j % ch;
+  }
+  const int tn = chunk >> 2, wc = chunk & 3;
+  const int row0 = panel * QM;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int prow = lane >> 3, pslot = lane & 7;
+  auto dma16 = [&](const void* g, const char* lds_dst) {
+    const uint32_t m = (uint32_t)(uintptr_t)LDS_PTR(lds_dst);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+#pragma clang diagnostic pop
+  };
+  const bf16_t* a_panel = a_tiled ? A + ((size_t)(row0 >> 7) * (K >> 6) << 13) + ((size_t)(row0 & 127) << 6)
+                                  : A + (size_t)row0 * lda;
+  const int ld_a = a_tiled ? 64 : lda, a_kstep = a_tiled ? 8192 : PK;
+  const bf16_t* w_chunk = W + (size_t)chunk * QN * ldw;
+  auto stage = [&](int kt, int buf) {     // 4 DMA instructions per wave: 2 row groups of A, 2 of W
+    char* base = smem + buf * QSTAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = w + 4 * j, row = 8 * g + prow;
+      dma16(a_panel + (size_t)kt * a_kstep + (size_t)row * ld_a + swz128(row, pslot) * 8, base + g * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = w + 4 * j, row = 8 * g + prow;
+      dma16(w_chunk + (size_t)row * ldw + kt * PK + swz128(row, pslot) * 8, base + QM * 128 + g * 1024);
+    }
+  };
+
+  const int nt = K / PK;
+  for (int s = 0; s < QD; ++s)
+    if (s < nt) stage(s, s);
+
+  f32x4_t acc[2][2];       // [nh][i]: lane holds n = 4 fq .. +3 of 16-col block (nh, i), row fr of this wave's 16-row block
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[nh][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int lsw = (fr >> 1) & 7;
+  const int c0 = (fq ^ lsw) * 16, c1 = ((4 + fq) ^ lsw) * 16;
+  const int a_rd = (w * 16 + fr) * 128, b_rd = QM * 128 + fr * 128;
+  for (int t = 0; t < nt; ++t) {
+    // K tile t has landed for this wave: at most the tiles issued after it (4 DMA instructions each) are outstanding
+    const int rem = nt - 1 - t < QD - 1 ? nt - 1 - t : QD - 1;
+    switch (rem) {
+      VMCNT_CASE(0) VMCNT_CASE(1) VMCNT_CASE(2) VMCNT_CASE(3) VMCNT_CASE(4) VMCNT_CASE(5)
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (QD - 1)) : "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();   // ... for every wave; and K tile t - 1 has been read by all: its buffer is free
+    if (t + QD < nt) stage(t + QD, (t + QD) % QNST);
+    const char* buf = smem + (t % QNST) * QSTAGE;
+    opx8_t af[2], bf[2][2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf[nh][i][0] = *reinterpret_cast<const opx8_t*>(buf + b_rd + nh * 4096 + i * 2048 + c0);
+        bf[nh][i][1] = *reinterpret_cast<const opx8_t*>(buf + b_rd + nh * 4096 + i * 2048 + c1);
+      }
+    af[0] = *reinterpret_cast<const opx8_t*>(buf + a_rd + c0);
+    af[1] = *reinterpret_cast<const opx8_t*>(buf + a_rd + c1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[nh][i] = MFMA_16x16x32(bf[nh][i][ks], af[ks], acc[nh][i]);
+  }
+
+  // ---- epilogue: the steps of gemm4_lnout_kernel for 16-row block m = w of column wave wc of tile tn
+  const int m = w;
+  const int n_base = chunk * QN;
+  const int r256 = row0 & 255, mh = r256 >> 7, wr256 = (r256 >> 6) & 1;
+  const int tm = row0 >> 8;
+  const size_t wave_tile = (((size_t)tm * tiles_n + tn) * 8 + wr256 * 4 + wc) * 8192 + (size_t)mh * 4 * 1024 + m * 1024;
+  f32x4_t bv[2][2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bv[nh][i] = *reinterpret_cast<const f32x4_t*>(bias + n_base + nh * 32 + i * 16 + fq * 4);
+  // (1) v = (acc + bias) + residual
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    float r[2][4];
+    if (res_mode == 2) {
+      const float* rt = reinterpret_cast<const float*>(resv) + wave_tile + nh * 512 + lane * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(rt + i * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[i][e] = v[e];
+      }
+    } else if (res_mode == 1) {
+      const f16x8_t v = *reinterpret_cast<const f16x8_t*>(reinterpret_cast<const uint16_t*>(resv) + wave_tile + nh * 512 + lane * 8);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[i][e] = (float)v[i * 4 + e];
+    } else {
+      const uint16_t* rr = reinterpret_cast<const uint16_t*>(resv) + (size_t)(row0 + m * 16 + fr) * ldres + n_base + nh * 32 + fq * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f16x4_t v = *reinterpret_cast<const f16x4_t*>(rr + i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[i][e] = (float)v[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[nh][i][e] = (acc[nh][i][e] + bv[nh][i][e]) + r[i][e];
+  }
+  // (2) per-row (sum, sum of squares) over the chunk's 64 columns: what a column wave of the other kernels forms
+  f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x2_t lo2 = {acc[nh][i][0], acc[nh][i][1]};
+      const f32x2_t hi2 = {acc[nh][i][2], acc[nh][i][3]};
+      s2 += lo2; s2 += hi2;
+      q2 = __builtin_elementwise_fma(lo2, lo2, q2);
+      q2 = __builtin_elementwise_fma(hi2, hi2, q2);
+    }
+  float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
+  sm = xor16_sum4(sm); sq = xor16_sum4(sq);
+  sm = xor32_sum4(sm); sq = xor32_sum4(sq);
+  // (3) published per chunk (agent-scope stores), then the workgroup's flag
+  unsigned long long* part64 = reinterpret_cast<unsigned long long*>(lo.part);
+  const size_t part_base = ((size_t)tm * chunks_n) * 256 + r256;       // + chunk * 256 + row of the panel
+  if (fq == 0) {
+    const float2 P = make_float2(sm, sq);
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &P, 8);
+    __hip_atomic_store(part64 + part_base + (size_t)chunk * 256 + m * 16 + fr, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int flag_id = panel * chunks_n + chunk;
+  if (tid == 0 && !(lo.test_drop && flag_id == 1))
+    __hip_atomic_store(lo.flags + flag_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (4) one lane per partner chunk polls its flag, bounded and sticky
+  if (tid < chunks_n && tid != chunk) {
+    const uint32_t* f = lo.flags + panel * chunks_n + tid;
+    int spins = 0;
+    bool dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
+    while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lo.epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 20)) { atomicOr(lo.err, 2); break; }
+      if ((spins & 255) == 0) dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
+    }
+  }
+  __syncthreads();
+  // (5) the row's totals: chunks of a 256-column group as (c0 + c1) + (c2 + c3), the groups in index order
+  float2* stat_lds = reinterpret_cast<float2*>(smem + QNST * QSTAGE);     // [64] (mean, rstd)
+  if (tid < 64) {
+    float2 T = make_float2(0.f, 0.f);
+    for (int k = 0; k < tiles_n; ++k) {
+      float2 p[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned long long bits = __hip_atomic_load(part64 + part_base + (size_t)(4 * k + c) * 256 + tid,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_memcpy(&p[c], &bits, 8);
+      }
+      const float2 P = make_float2((p[0].x + p[1].x) + (p[2].x + p[3].x), (p[0].y + p[1].y) + (p[2].y + p[3].y));
+      T.x += P.x; T.y += P.y;
+    }
+    const float inv_n = 1.0f / (float)(tiles_n * PN);
+    const float mean = T.x * inv_n;
+    const float var = fmaxf(fmaf(T.y, inv_n, -mean * mean), 0.f);
+    stat_lds[tid] = make_float2(mean, 1.0f / sqrtf(var + lo.eps));
+  }
+  __syncthreads();
+  // (6) normalise and store, as gemm4_lnout_kernel
+  const float2 st = stat_lds[m * 16 + fr];
+  uint16_t* xrow = reinterpret_cast<uint16_t*>(out) + (size_t)(row0 + m * 16 + fr) * ldo + n_base + fq * 4;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    f16x8_t hv;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(ln_gamma + n_base + nh * 32 + i * 16 + fq * 4);
+      const f32x4_t be = *reinterpret_cast<const f32x4_t*>(ln_beta + n_base + nh * 32 + i * 16 + fq * 4);
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = ln_apply(acc[nh][i][e], st.x, st.y, gv[e], be[e]);
+        hv[i * 4 + e] = (_Float16)y[e];
+      }
+      *reinterpret_cast<uint2*>(xrow + nh * 32 + i * 16) = make_uint2(pack_op2(y[0], y[1]), pack_op2(y[2], y[3]));
+      if (out_mode == 2)
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(lo.xres_out) + wave_tile + nh * 512 + i * 256 + lane * 4) =
+            (f32x4_t){y[0], y[1], y[2], y[3]};
+    }
+    if (out_mode == 1)
+      *reinterpret_cast<u32x4_t*>(lo.xres_out + wave_tile + nh * 512 + lane * 8) = *reinterpret_cast<const u32x4_t*>(&hv);
+  }
+}
+#undef VMCNT_CASE
+
 }  // namespace
 
-// Takes an EPI_BIAS_LNOUT problem when the caller allows it (LnOutArgs::small_ok: flags sized for 64-row panels) and
-// the whole grid is resident at once; otherwise returns hipErrorNotReady and the caller runs the ping-pong kernel.
+// Takes an EPI_BIAS_LNOUT problem when the caller allows it (LnOutArgs::small_ok: 1 = flags sized for 64-row panels,
+// 2 = flags and partials sized for 64 x 64 tiles too) and the whole grid is resident at once — the 64 x 64 form when
+// its grid fits, else the 64 x 256 form; otherwise returns hipErrorNotReady and the caller runs the ping-pong kernel.
 hipError_t KSET::launch_gemm4_lnout(const GemmArgs& g, hipStream_t st) {
   if (g.epi != EPI_BIAS_LNOUT || !g.lnout.small_ok || g.M % 256 || g.N % 256 || g.K % 128) return hipErrorNotReady;
   const int tiles_n = g.N / PN, grid = (g.M / PM) * tiles_n;
@@ -294,10 +530,15 @@ hipError_t KSET::launch_gemm4_lnout(const GemmArgs& g, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4_lnout_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4n_lnout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ);
+    if (e != hipSuccess) return e;
     return hipDeviceGetAttribute(val, hipDeviceAttributeMultiprocessorCount, dev);
   }, &n_cu);
   if (e0 != hipSuccess) return e0;
-  if (grid > n_cu || tiles_n > 8) return hipErrorNotReady;     // partners must be co-resident: one workgroup per CU
+  if (tiles_n > 8) return hipErrorNotReady;
+  const int grid_n = (g.M / QM) * (g.N / QN);
+  const bool narrow = g.lnout.small_ok >= 2 && grid_n <= n_cu && grid_n % 8 == 0;
+  if (!narrow && grid > n_cu) return hipErrorNotReady;          // partners must be co-resident: one workgroup per CU
   int res_mode, out_mode;
   const void* res = g.res;
   if (g.lnout.res_f32) {
@@ -321,6 +562,12 @@ hipError_t KSET::launch_gemm4_lnout(const GemmArgs& g, hipStream_t st) {
   if (!g.lnout.part || !g.lnout.flags || !g.lnout.err || !res) return hipErrorInvalidValue;
   const void* W = g.w_tiled ? g.W_rowmajor : g.W;      // this kernel reads the row-major weight
   if (!W) return hipErrorNotReady;
+  if (narrow) {
+    hipLaunchKernelGGL(gemm4n_lnout_kernel, dim3(grid_n), dim3(256), LDSQ, st, static_cast<const bf16_t*>(g.A),
+                       static_cast<const bf16_t*>(W), g.bias, res, g.out, g.K, g.lda, g.w_tiled ? g.K : g.ldw, g.ldo, g.ldres, tiles_n,
+                       g.a_tiled ? 1 : 0, g.ln_gamma, g.ln_beta, g.lnout, res_mode, out_mode, g.M / QM);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(gemm4_lnout_kernel, dim3(grid), dim3(512), LDS4, st, static_cast<const bf16_t*>(g.A),
                      static_cast<const bf16_t*>(W), g.bias, res, g.out, g.K, g.lda, g.w_tiled ? g.K : g.ldw, g.ldo, g.ldres, tiles_n,
                      g.a_tiled ? 1 : 0, g.ln_gamma, g.ln_beta, g.lnout, res_mode, out_mode);

@@ -28,8 +28,10 @@ struct LnOutArgs {         // EPI_BIAS_LNOUT
   uint32_t test_drop = 0;  // diagnostic (CLIP_AMD_TEST_DROP_PUBLISH=1): tile 1 never publishes its flag
   bool res_f32 = false;    // fp16 operand set only (CLIP_PRECISION_F16R): res and xres_out are FP32, tiled by
                            // xres32_tiled_offset (res_tiled must be set) — the residual stream never leaves fp32
-  bool small_ok = false;   // `flags` holds (M / 64) * (N / 256) entries (4x the ping-pong kernel's need): calls whose whole
-                           // grid of 64-row tiles is resident at once may run on gemm4.hip's kernel (same bits)
+  int small_ok = 0;        // 1: `flags` holds (M / 64) * (N / 256) entries (4x the ping-pong kernel's need): calls whose whole
+                           // grid of 64-row tiles is resident at once may run on gemm4.hip's kernels (same bits);
+                           // 2: `flags` holds (M / 64) * (N / 64) entries and `part` (M / 256) * (N / 64) * 256 pairs as well
+                           // (16x / 4x): the 64 x 64-tile form may run too
 };
 
 struct GemmArgs {

@@ -214,8 +214,8 @@ def test_f16r_fused_flow_equals_unfused_flow(golden, name):
 
 @pytest.mark.parametrize("precision", ["bf16", "f16", "f16r"])
 def test_small_m_fused_gemm_same_bits(precision, monkeypatch):
-    """Calls of a few hundred to a few thousand tokens run their fused-LayerNorm GEMMs on 64 x 256 tiles (gemm4.hip)
-    instead of the ping-pong kernel's 256 x 256: the logits must be the SAME BITS, for the reference's batches of 8
+    """Calls of a few hundred to a few thousand tokens run their fused-LayerNorm GEMMs on 64 x 64 or 64 x 256 tiles
+    (gemm4.hip) instead of the ping-pong kernel's 256 x 256: the logits must be the SAME BITS, for the reference's batches of 8
     (apply_bert_unlabeled.py:92-110), for a mid-sized packed step and against a big step that the ping-pong kernel
     takes in both runs."""
     cfg = BertConfig()
@@ -224,13 +224,16 @@ def test_small_m_fused_gemm_same_bits(precision, monkeypatch):
     rows = scoring.PackedRows(flat, off)
     small = [rows.flat[rows.offsets[i]:rows.offsets[i + 1]] for i in range(24)]
     out = {}
-    for flag in ("1", "0"):
+    for flag in ("2", "1", "0"):       # 2 (the default): 64 x 64 tiles where their grid fits (<= 1280 tokens), else 64 x 256
         monkeypatch.setenv("CLIP_AMD_SMALL_M", flag)
         m = _model(cfg, sd, 2, precision, tokens=131072)
         big = scoring.BulkScorer(m, keep_logits=True).score(rows).logits                          # one step of ~78 k tokens
         mid = scoring.BulkScorer(m, keep_logits=True, tokens_per_step=4096).score(rows).logits   # steps of <= 4096 tokens
+        tiny = scoring.BulkScorer(m, keep_logits=True, tokens_per_step=1024).score(rows).logits  # steps of <= 1024 tokens
         m._drop_engine()
-        out[flag] = (big, mid, _logits(cfg, sd, small, 2, precision, 8))                          # batches of 8 padded rows
-    for a, b in zip(out["1"], out["0"]):
-        assert np.array_equal(a, b)
-    assert np.array_equal(out["1"][0], out["1"][1]) and np.array_equal(out["1"][0][:24], out["1"][2])
+        out[flag] = (big, mid, tiny, _logits(cfg, sd, small, 2, precision, 8))                    # batches of 8 padded rows
+    for flag in ("2", "1"):
+        for a, b in zip(out[flag], out["0"]):
+            assert np.array_equal(a, b), flag
+    assert np.array_equal(out["2"][0], out["2"][1]) and np.array_equal(out["2"][0], out["2"][2])
+    assert np.array_equal(out["2"][0][:24], out["2"][3])
