@@ -534,7 +534,7 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
       HIP_TRY(res_gemm(e->mid_rows, L.wo2, L.bo2, n_seqs, I, e->pre_rows[0], e->stats_rows[0], e->pre_rows[1], nullptr));
     }
-    {
+    if (head_kind != 0) {
       ProfScope ps(e, CLIP_KIND_LAST_LAYER_ROWS, st);
       HIP_TRY(KS::launch_layernorm(e->pre_rows[1], L.ln2g, L.ln2b, c.layer_norm_eps, e->rows, n_seqs, H, st));
     }
@@ -542,7 +542,13 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   ProfScope ps_head(e, CLIP_KIND_HEAD, st);
   if (trim) {
     if (head_kind == 0) {
-      HIP_TRY(KS::launch_classifier(e->rows, nullptr, e->wcls, e->bcls, logits, n_seqs, H, c.num_labels, st));
+      // last LayerNorm + classifier + the guard below in one kernel (the last kernel of the call)
+      const LayerW& L = e->layers[c.num_layers - 1];
+      HIP_TRY(KS::launch_ln_head(e->pre_rows[1], L.ln2g, L.ln2b, c.layer_norm_eps, n_seqs, H, e->wcls, e->bcls,
+                                 c.num_labels, logits, e->dev_err, st));
+      e->last_full = false;
+      e->last_tokens = T;
+      return CLIP_OK;
     } else {
       g = GemmArgs{e->rows, e->wpool, e->bpool, nullptr, e->pooled, n_seqs, H, H, H, H, H, 0,
                    EPI_BIAS_TANH, false};

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void gemm4n_lnout_kernel(
     }
   };
 
-  const int nt = K / PK;
+  const int nt = K / PK;   // even (K % 128 == 0)
   for (int s = 0; s < QD; ++s)
     if (s < nt) stage(s, s);
 
@@ -356,17 +356,21 @@ __global__ __launch_bounds__(256) void gemm4n_lnout_kernel(
   const int lsw = (fr >> 1) & 7;
   const int c0 = (fq ^ lsw) * 16, c1 = ((4 + fq) ^ lsw) * 16;
   const int a_rd = (w * 16 + fr) * 128, b_rd = QM * 128 + fr * 128;
-  for (int t = 0; t < nt; ++t) {
-    // K tile t has landed for this wave: at most the tiles issued after it (4 DMA instructions each) are outstanding
-    const int rem = nt - 1 - t < QD - 1 ? nt - 1 - t : QD - 1;
+  // One wave per SIMD: the LDS reads of K tile t + 1 are issued before the MFMAs of tile t (two register sets), so the
+  // two overlap inside the wave.  Step t: the reads of tile t - 1 are complete (they ran under the MFMAs of t - 2),
+  // tile t has landed, barrier: every wave holds tile t - 1 in registers, so its buffer takes tile t + 7.
+  auto top = [&](int t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rem = nt - 1 - t < QD - 1 ? nt - 1 - t : QD - 1;   // tiles issued after tile t: 4 DMA instructions each
     switch (rem) {
       VMCNT_CASE(0) VMCNT_CASE(1) VMCNT_CASE(2) VMCNT_CASE(3) VMCNT_CASE(4) VMCNT_CASE(5)
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (QD - 1)) : "memory"); break;
     }
-    __builtin_amdgcn_s_barrier();   // ... for every wave; and K tile t - 1 has been read by all: its buffer is free
+    __builtin_amdgcn_s_barrier();
     if (t + QD < nt) stage(t + QD, (t + QD) % QNST);
+  };
+  auto rd = [&](int t, opx8_t (&af)[2], opx8_t (&bf)[2][2][2]) {
     const char* buf = smem + (t % QNST) * QSTAGE;
-    opx8_t af[2], bf[2][2][2];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
@@ -376,12 +380,27 @@ __global__ __launch_bounds__(256) void gemm4n_lnout_kernel(
       }
     af[0] = *reinterpret_cast<const opx8_t*>(buf + a_rd + c0);
     af[1] = *reinterpret_cast<const opx8_t*>(buf + a_rd + c1);
+  };
+  auto mm = [&](const opx8_t (&af)[2], const opx8_t (&bf)[2][2][2]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[nh][i] = MFMA_16x16x32(bf[nh][i][ks], af[ks], acc[nh][i]);
+  };
+  opx8_t afA[2], bfA[2][2][2], afB[2], bfB[2][2][2];
+  top(0);
+  rd(0, afA, bfA);
+  for (int t = 1; t < nt; t += 2) {
+    top(t);
+    rd(t, afB, bfB);
+    mm(afA, bfA);               // tile t - 1
+    if (t + 1 < nt) {
+      top(t + 1);
+      rd(t + 1, afA, bfA);
+    }
+    mm(afB, bfB);               // tile t
   }
 
   // ---- epilogue: the steps of gemm4_lnout_kernel for 16-row block m = w of column wave wc of tile tn

@@ -127,6 +127,10 @@ hipError_t launch_mean_loss(const float* row_loss, int n, float* loss, int accum
                                      bool out_f32 = false, float* stats = nullptr,                   \
                                      uint16_t* res16 = nullptr);                                     \
   /* logits[i] = Wc . x[rows ? rows[i] : i] + bc     (Wc [L,H] f32, x 16-bit or fp32) */             \
+  /* last LayerNorm of the trimmed forward + classifier + the guard of launch_poison_logits, one kernel */ \
+  static hipError_t launch_ln_head(const float* x, const float* gamma, const float* beta, float eps, \
+                                   int n, int H, const float* Wc, const float* bc, int L,            \
+                                   float* logits, int32_t* err, hipStream_t st);                     \
   static hipError_t launch_classifier(const void* x, const int32_t* rows, const float* Wc,           \
                                       const float* bc, float* logits, int n, int H, int L,           \
                                       hipStream_t st, bool f32 = false);

@@ -183,6 +183,73 @@ __global__ __launch_bounds__(256) void classifier_kernel(const void* __restrict_
   }
 }
 
+// The end of the trimmed forward in ONE kernel, one wave per sentence: the last LayerNorm (arithmetic of ln_finish,
+// output rounded to the 16-bit operand type as when it is stored), the classifier Linear(H -> L) on it (ref:
+// sentclf/bert_model.py:91) and the guard of poison_logits_kernel.  Every load of a lane is independent of the others
+// (compile-time trip counts), so the kernel costs one memory latency instead of one per 128 columns and per launch.
+template <int VEC, int NIT>
+__global__ __launch_bounds__(256) void ln_head_kernel(const float* __restrict__ xin, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, int n, int H,
+                                                      const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                      int L, float* __restrict__ logits, int32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float x[NIT][VEC];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s += x[it][v];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float d = x[it][v] - mean;
+      q += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (it * 64 + lane) * VEC;
+    float g[VEC], b[VEC], y[VEC];
+    load_vec<VEC>(gamma + e, g);
+    load_vec<VEC>(beta + e, b);
+#pragma unroll
+    for (int v = 0; v < VEC; v += 2) {
+      const uint32_t u = pack_op2(ln_apply(x[it][v], mean, rstd, g[v], b[v]), ln_apply(x[it][v + 1], mean, rstd, g[v + 1], b[v + 1]));
+      y[v] = op2_lo(u);
+      y[v + 1] = op2_hi(u);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < L) {
+        float w[VEC];
+        load_vec<VEC>(Wc + (size_t)j * H + e, w);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[j] += y[v] * w[v];
+      }
+    }
+  }
+  const bool void_call = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < L) {
+      float v = wave_sum(acc[j]) + bc[j];
+      if (lane == 0) {
+        if (void_call) v = __builtin_nanf("");
+        else if (!__builtin_isfinite(v)) atomicOr(err, 8);
+        logits[(size_t)row * L + j] = v;
+      }
+    }
+  }
+}
+
 // ref: sentclf/bert_model.py:52 — where(input_ids == sep)[1].reshape(-1, 2n+1)[:, n], per row
 __global__ __launch_bounds__(64) void focus_index_kernel(const int32_t* __restrict__ ids,
                                                          const int32_t* __restrict__ cu, int n_seqs,
@@ -524,6 +591,17 @@ hipError_t launch_gather_rows(const void* src, const int32_t* rows, void* dst, i
 }
 
 #endif
+
+hipError_t KSET::launch_ln_head(const float* x, const float* gamma, const float* beta, float eps, int n, int H,
+                                const float* Wc, const float* bc, int L, float* logits, int32_t* err, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (L > 8 || L < 1) return hipErrorInvalidValue;
+  return ln_dispatch(H, false, [&]<int VEC, int NIT, bool F32>() {
+    hipLaunchKernelGGL((ln_head_kernel<VEC, NIT>), dim3((n + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, n, H, Wc,
+                       bc, L, logits, err);
+    return hipGetLastError();
+  });
+}
 
 hipError_t KSET::launch_classifier(const void* x, const int32_t* rows, const float* Wc,
                              const float* bc, float* logits, int n, int H, int L, hipStream_t st,
