@@ -293,8 +293,131 @@ hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- at most 32 rows: the trimmed last layer of ONE batch of the reference's loop (8 sentences -> 8 rows) ----
+// With 128 x 128 tiles such a call is N / 128 workgroups that each pull 128 weight rows AND 128 (clamped, repeated)
+// activation rows per K tile through one CU's LDS-DMA intake (~55 GB/s): 31 us for the FFN-down rows of a batch of 8.
+// Here a workgroup owns 16 rows x 16 columns: N / 16 workgroups, 4 KiB per K tile (one 1-KiB DMA piece per wave: waves
+// 0-1 the activation rows, 2-3 the weight rows) through a 16-stage ring; wave 0 alone reads the fragments and issues
+// the 2 MFMAs per K tile.  Same MFMA, same K order into one accumulator, same epilogue expressions as the tile kernel
+// above: the SAME BITS (tests/test_gpu_kernels.py::test_rows16_gemm_same_bits_as_tile_kernel).
+constexpr int R16_NST = 16, R16_D = R16_NST - 1, R16_STAGE = 4096;
+
+#define R16_VMCNT(n) case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); break;
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_rows16_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+    const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw, int ldo, int ldres,
+    const float2* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
+    const int32_t* __restrict__ res_index, int res_tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[R16_NST * R16_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N >> 4;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int mb = tm * 16, nb = tn * 16;
+  // this wave's DMA piece: 8 rows x 128 B of the activation (w < 2) or of the weight (w >= 2)
+  const int prow = (w & 1) * 8 + (lane >> 3);
+  const bf16_t* src = (w < 2 ? A + (size_t)min(mb + prow, M - 1) * lda : W + (size_t)(nb + prow) * ldw) +
+                      swz128(prow, lane & 7) * 8;
+  auto stage = [&](int kt, int buf) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src + kt * 64), LDS_PTR(smem + buf * R16_STAGE + w * 1024), 16, 0, 0);
+  };
+  const int nt = K >> 6;
+  for (int s = 0; s < R16_D; ++s)
+    if (s < nt) stage(s, s);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int lsw = (fr >> 1) & 7;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave 0 holds K tile t - 1 in registers: its buffer is free
+    const int rem = nt - 1 - t < R16_D - 1 ? nt - 1 - t : R16_D - 1;     // one DMA instruction per wave and K tile
+    switch (rem) {
+      R16_VMCNT(0) R16_VMCNT(1) R16_VMCNT(2) R16_VMCNT(3) R16_VMCNT(4) R16_VMCNT(5) R16_VMCNT(6) R16_VMCNT(7)
+      R16_VMCNT(8) R16_VMCNT(9) R16_VMCNT(10) R16_VMCNT(11) R16_VMCNT(12) R16_VMCNT(13)
+      default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    }
+    __syncthreads();
+    if (t + R16_D < nt) stage(t + R16_D, (t + R16_D) % R16_NST);
+    if (w == 0) {
+      const char* base = smem + (t % R16_NST) * R16_STAGE;
+      opx8_t af[2], wf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((ks * 4 + fq) ^ lsw) * 16;
+        wf[ks] = *reinterpret_cast<const opx8_t*>(base + 2048 + fr * 128 + coff);
+        af[ks] = *reinterpret_cast<const opx8_t*>(base + fr * 128 + coff);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc = MFMA_16x16x32(wf[ks], af[ks], acc);
+    }
+  }
+  if (w != 0) return;
+  // ---- epilogue: the lane holds n = nb + 4 fq .. +3 of row m = mb + fr; the tile kernel's expressions, in its order
+  const int m = mb + fr, n = nb + fq * 4;
+  if (m >= M) return;
+  const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+  float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
+  if (EPI == EPI_BIAS_GELU) {
+    if (OUT_F32) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    else { v0 = gelu_erf_bf16out(v0); v1 = gelu_erf_bf16out(v1); v2 = gelu_erf_bf16out(v2); v3 = gelu_erf_bf16out(v3); }
+  } else if (EPI == EPI_BIAS_TANH) {
+    v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3);
+  }
+  if (!OUT_F32) {
+    uint2 o = make_uint2(pack_op2(v0, v1), pack_op2(v2, v3));
+    if (EPI == EPI_BIAS_RES) {
+      const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(resv) + (size_t)m * ldres + n);
+      o = make_uint2(pack_op2(op2_lo(o.x) + op2_lo(r.x), op2_hi(o.x) + op2_hi(r.x)),
+                     pack_op2(op2_lo(o.y) + op2_lo(r.y), op2_hi(o.y) + op2_hi(r.y)));
+    }
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldo + n) = o;
+    return;
+  }
+  float4 v = make_float4(v0, v1, v2, v3);
+  if (EPI == EPI_BIAS_LNRES) {
+    const int rr = res_index ? res_index[m] : m;
+    const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) + (size_t)rr * ldres + n);
+    const float2 sv = ln_stats[rr];
+    const float4 gv = *reinterpret_cast<const float4*>(ln_gamma + n);
+    const float4 be = *reinterpret_cast<const float4*>(ln_beta + n);
+    v.x += ln_apply(rv.x, sv.x, sv.y, gv.x, be.x); v.y += ln_apply(rv.y, sv.x, sv.y, gv.y, be.y);
+    v.z += ln_apply(rv.z, sv.x, sv.y, gv.z, be.z); v.w += ln_apply(rv.w, sv.x, sv.y, gv.w, be.w);
+  }
+  if (EPI == EPI_BIAS_RES16) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const int rr = res_index ? res_index[m] : m;
+    if (res_tiles_n < 0) {
+      const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(resv) +
+                                                          xres32_tiled_offset(rr, n, -res_tiles_n));
+      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    } else {
+      const size_t ro = res_tiles_n > 0 ? xres_tiled_offset(rr, n, res_tiles_n) : (size_t)rr * ldres + n;
+      const f16x4_t rv = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const uint16_t*>(resv) + ro);
+      v.x += (float)rv[0]; v.y += (float)rv[1]; v.z += (float)rv[2]; v.w += (float)rv[3];
+    }
+  }
+  if (EPI == EPI_BIAS_RES) {
+    const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(resv) + (size_t)m * ldres + n);
+    v.x += op2_lo(rv.x); v.y += op2_hi(rv.x);
+    v.z += op2_lo(rv.y); v.w += op2_hi(rv.y);
+  }
+  *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * ldo + n) = v;
+}
+#undef R16_VMCNT
+
+template <int EPI, bool OUT_F32>
+hipError_t launch_rows16(const GemmArgs& g, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_rows16_kernel<EPI, OUT_F32>), dim3(((g.M + 15) / 16) * (g.N / 16)), dim3(256), 0, st,
+                     static_cast<const bf16_t*>(g.A), static_cast<const bf16_t*>(g.W), g.bias, g.res, g.out, g.M, g.N,
+                     g.K, g.lda, g.ldw, g.ldo, g.ldres, reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma,
+                     g.ln_beta, g.res_index, g.res_tiles_n);
+  return hipGetLastError();
+}
+
 template <int EPI, bool OUT_F32>
 hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
+  if (g.tile == 0 && g.M <= 32 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_rows16<EPI, OUT_F32>(g, st);   // a batch's rows
   // big tile once it fills the chip about once over; the small tile otherwise
   const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
   if (g.tile == 256 || (g.tile == 0 && big_tiles >= 192 && g.N % 256 == 0))

@@ -65,6 +65,63 @@ def test_gemm_matches_fp32_reference(lib, M, N, K, epi, out_f32, tile):
     assert (out - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M", [1, 8, 16, 23, 32])
+@pytest.mark.parametrize("N,K,epi,out_f32", [
+    (768, 768, 0, False),       # q projection of the focus rows
+    (3072, 768, 1, False),      # FFN up + erf-GELU on the rows
+    (768, 3072, 2, True),       # + bf16 residual, fp32 out
+    (768, 768, 2, False),       # + bf16 residual, 16-bit out
+    (768, 768, 3, False),       # pooler tanh
+    (768, 768, 1, True),        # exact-erf GELU, fp32 out (LM-head transform)
+    (256, 128, 0, True),
+])
+def test_rows16_gemm_same_bits_as_tile_kernel(lib, M, N, K, epi, out_f32):
+    """Calls of at most 32 rows (the trimmed last layer of one batch of the reference's loop) run on 16 x 16 tiles
+    (gemm_rows16_kernel): the result must be the SAME BITS as the 128 x 128 tile kernel's, which takes the same rows
+    when they come in a bigger batch, and within the fp32-reference tolerance."""
+    g = torch.Generator(device="cpu").manual_seed(M * 11 + N + K + epi)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    W[:, 0] += torch.arange(N, device="cuda").to(torch.bfloat16) * 0.01
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if epi == 2 else None
+    small = _gemm(lib, A, W, bias, res, epi, out_f32, 0)          # auto: M <= 32 -> the 16-row kernel
+    tile = _gemm(lib, A, W, bias, res, epi, out_f32, 128)
+    assert torch.isfinite(small.float()).all()
+    assert torch.equal(small, tile)
+    ref = A.float() @ W.float().T + bias
+    ref = torch.nn.functional.gelu(ref) if epi == 1 else ref + res.float() if epi == 2 else torch.tanh(ref) if epi == 3 else ref
+    # 16-bit out: one rounding (2^-8 relative), two when the 16-bit residual is added to the rounded product
+    assert (small.float() - ref).abs().max().item() < 2e-3 + (0 if out_f32 else (8e-3 if epi == 2 else 4e-3) * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [8, 30])
+def test_rows16_gemm_layernorm_residual_same_bits(lib, M):
+    """the indexed LayerNorm-residual epilogue (last FFN-down of the trimmed layer) on the 16-row kernel vs the tile kernel"""
+    N, K, R = 768, 3072, 500
+    g = torch.Generator(device="cpu").manual_seed(M)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    pre = (torch.randn(R, N, generator=g) * 1.5 + 0.2).cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    idx = torch.randint(0, R, (M,), generator=g).to(torch.int32).cuda()
+    xb = torch.empty(R, N, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(R, 2, device="cuda")
+    _lib.check(lib.clip_layernorm_stats(_lib.ptr(pre), _lib.ptr(gamma), _lib.ptr(beta), 1e-12, _lib.ptr(xb),
+                                        _lib.ptr(stats), R, N, _lib.stream_ptr()))
+    outs = []
+    for t in (0, 128):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.clip_gemm_bf16_lnres(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(pre), _lib.ptr(stats),
+                                            _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(idx), _lib.ptr(out), M, N, K,
+                                            K, K, N, N, t, _lib.stream_ptr()))
+        _sync()
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K,epi,out_f32", [
     (256, 256, 128, 0, True),         # one tile, two K steps
     (2048, 768, 768, 2, True),        # fewer tiles than CUs: some workgroups idle

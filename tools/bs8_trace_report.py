@@ -10,7 +10,7 @@ import pandas as pd
 t = pd.read_csv(sys.argv[1]).sort_values("Start_Timestamp").reset_index(drop=True)
 t["k"] = t.Kernel_Name.map(lambda n: re.sub(r"\(anonymous namespace\)::|void ", "", n)[:64])
 t["dur"] = (t.End_Timestamp - t.Start_Timestamp) / 1e3
-pz = t.index[t.k.str.startswith("poison")].tolist()
+pz = t.index[t.k.str.startswith("ln_head") | t.k.str.startswith("poison")].tolist()      # last kernel of a forward
 lo, hi = len(pz) // 2 + 20, len(pz) - 10          # batches of the timed (second) pass
 if "--timeline" in sys.argv:
     w = t.iloc[pz[lo] + 1:pz[lo + 1] + 3]
