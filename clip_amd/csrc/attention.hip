@@ -367,22 +367,30 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
 #pragma unroll
   for (int e = 0; e < 8; ++e) qv[e] = q_s[c * 8 + e];
   const int n_it = (len + 7) >> 3;
-  for (int it = 0; it < n_it; ++it) {
-    const int key = it * 8 + g;
-    float d = 0.f;
-    if (key < len) {
-      const uint4 kv = *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8);
-      const uint32_t wds[4] = {kv.x, kv.y, kv.z, kv.w};
+  // four key rows per lane in flight (a batch of 8 sentences is 96 waves on the whole chip: the loop is a chain of
+  // load latencies, not bandwidth); the arithmetic per key, and its order, are unchanged
+  for (int it0 = 0; it0 < n_it; it0 += 4) {
+    uint4 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = (it0 + u) * 8 + g;
+      kv[u] = key < len ? *reinterpret_cast<const uint4*>(kbase + (size_t)key * ld + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = (it0 + u) * 8 + g;
+      float d = 0.f;
+      const uint32_t wds[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         d = fmaf(op2_lo(wds[e]), qv[2 * e], d);
         d = fmaf(op2_hi(wds[e]), qv[2 * e + 1], d);
       }
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if (c == 0 && key < len) p_s[key] = d * LOG2E;
     }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (c == 0 && key < len) p_s[key] = d * LOG2E;
   }
   __syncthreads();
   float sc[8];
@@ -406,16 +414,24 @@ __global__ __launch_bounds__(64) void attention_focus_kernel(const bf16_t* __res
   __syncthreads();
   // o[dims 8c .. 8c+7] over this lane group's keys, then across the 8 groups (xor 8, 16, 32)
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int it = 0; it < n_it; ++it) {
-    const int key = it * 8 + g;
-    if (key < len) {
-      const float p = p_s[key];
-      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (size_t)key * ld + c * 8);
-      const uint32_t wds[4] = {vv.x, vv.y, vv.z, vv.w};
+  for (int it0 = 0; it0 < n_it; it0 += 4) {
+    uint4 vv[4];
+    float pw[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[2 * e] = fmaf(p, op2_lo(wds[e]), o[2 * e]);
-        o[2 * e + 1] = fmaf(p, op2_hi(wds[e]), o[2 * e + 1]);
+    for (int u = 0; u < 4; ++u) {
+      const int key = (it0 + u) * 8 + g;
+      vv[u] = key < len ? *reinterpret_cast<const uint4*>(vbase + (size_t)key * ld + c * 8) : make_uint4(0, 0, 0, 0);
+      pw[u] = key < len ? p_s[key] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if ((it0 + u) * 8 + g < len) {        // (a skipped key must not touch o: fmaf(0, 0, -0.0f) would flip a sign)
+        const uint32_t wds[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[2 * e] = fmaf(pw[u], op2_lo(wds[e]), o[2 * e]);
+          o[2 * e + 1] = fmaf(pw[u], op2_hi(wds[e]), o[2 * e + 1]);
+        }
       }
     }
   }

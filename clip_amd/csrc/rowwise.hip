@@ -195,9 +195,19 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
-  float x[NIT][VEC];
+  // every load of the kernel is issued up front (the row, the affine, the L classifier rows): one memory latency
+  float x[NIT][VEC], g[NIT][VEC], b[NIT][VEC], w[8][NIT][VEC];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) load_vec<VEC>(xin + (size_t)row * H + (it * 64 + lane) * VEC, x[it]);
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (it * 64 + lane) * VEC;
+    load_vec<VEC>(xin + (size_t)row * H + e, x[it]);
+    load_vec<VEC>(gamma + e, g[it]);
+    load_vec<VEC>(beta + e, b[it]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < L) load_vec<VEC>(Wc + (size_t)j * H + e, w[j][it]);
+  }
+  const bool void_call = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
@@ -216,27 +226,22 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const float* __restrict__ 
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int e = (it * 64 + lane) * VEC;
-    float g[VEC], b[VEC], y[VEC];
-    load_vec<VEC>(gamma + e, g);
-    load_vec<VEC>(beta + e, b);
+    float y[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v += 2) {
-      const uint32_t u = pack_op2(ln_apply(x[it][v], mean, rstd, g[v], b[v]), ln_apply(x[it][v + 1], mean, rstd, g[v + 1], b[v + 1]));
+      const uint32_t u = pack_op2(ln_apply(x[it][v], mean, rstd, g[it][v], b[it][v]),
+                                  ln_apply(x[it][v + 1], mean, rstd, g[it][v + 1], b[it][v + 1]));
       y[v] = op2_lo(u);
       y[v + 1] = op2_hi(u);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < L) {
-        float w[VEC];
-        load_vec<VEC>(Wc + (size_t)j * H + e, w);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[j] += y[v] * w[v];
+        for (int v = 0; v < VEC; ++v) acc[j] += y[v] * w[j][it][v];
       }
     }
   }
-  const bool void_call = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j < L) {
