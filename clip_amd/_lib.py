@@ -39,7 +39,7 @@ SIGNATURES = {
     "clip_focus_index": [_p, _p, _i32, _i32, _i32, _p, _p, _p],
     "clip_prepare_packed": [_p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_forward_packed": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p],
-    "clip_forward_padded": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "clip_forward_padded": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
     "clip_epilogue": [_p, _p, _f, _i32, _i32, _p, _p, _p, _p, _p],
     "clip_bce_loss": [_p, _p, _i32, _p, _p],
     "clip_mlm_head": [_p, _p, _p, _i32, _p, _p, _i32, _p],
@@ -97,6 +97,11 @@ def poll_errors(engine):
     """Read-and-clear the engine's device error word behind its latest forward; raises if non-zero."""
     flags = C.c_int32(0)
     check(load().clip_poll_errors(engine, C.byref(flags)))
+    raise_for_flags(flags)
+
+
+def raise_for_flags(flags):
+    """the exception of a non-zero device error word (clip_poll_errors, clip_forward_padded's error_flags)"""
     if flags.value & ERR_LN_TIMEOUT:
         raise RuntimeError(f"engine error word {flags.value}: a fused-LayerNorm exchange timed out (GPU shared "
                            "with other work? set CLIP_AMD_FUSED_LN=0 there); results of the call are void")

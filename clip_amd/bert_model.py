@@ -285,13 +285,14 @@ class _EngineModel:
             raise AttributeError("call set_sep_token_id() and set_n_context_sentences() first")
         with torch.cuda.device(self.device):
             # ONE call: packs the rows on the device (the key-padding mask becomes the packing), finds the focus [SEP],
-            # runs the encoder; one wait inside (the token count), one here (the engine's error word: an empty row, a
-            # wrong [SEP] count, non-finite logits)
+            # runs the encoder and returns the engine's error word (an empty row, a wrong [SEP] count, non-finite
+            # logits); its two waits (token count, end of the forward) spin on words the device writes to host memory
+            flags = C.c_int32(0)
             _lib.check(_lib.load().clip_forward_padded(
                 h, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(tt), _lib.ptr(pos), pos_stride, B, S,
                 int(getattr(self, "sep_token_id", None) or 0), int(n_ctx if n_ctx is not None else -1), self.head_kind,
-                _lib.ptr(logits), None, _lib.stream_ptr()))
-            _lib.poll_errors(h)
+                _lib.ptr(logits), None, C.byref(flags), _lib.stream_ptr()))
+            _lib.raise_for_flags(flags)
         if labels is None:
             return (logits,)
         if self.task != "multilabel":

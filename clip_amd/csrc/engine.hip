@@ -1,6 +1,7 @@
 // C ABI of libclip_amd.so (include/clip_amd.h): engine object = device weights + activation
 // workspace; clip_forward_packed chains the kernels of one BERT(+Context) forward on one stream.
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <atomic>
 #include <mutex>
@@ -88,10 +89,17 @@ struct clip_engine {
   uint16_t *xres_rm = nullptr;  // row-major: the embedding LayerNorm's copy, residual of the first fused GEMM
   float* xres32 = nullptr;      // F16R: the FP32 residual stream, tiled (xres32_tiled_offset), rewritten in place
   float* lnpart = nullptr;
+  unsigned long long* lnpart_tag = nullptr;   // epoch-tagged partials of the 64 x 64-tile small-M kernel (no flags there)
+  size_t lnpart_tag_bytes = 0;
   uint32_t* lnflags = nullptr;
   int32_t* dev_err = nullptr;
   // packed rows of clip_forward_padded: ids / type ids / position ids [max_tokens], cu [max_seqs + 1], focus [max_seqs]
   int32_t *pk_ids = nullptr, *pk_tt = nullptr, *pk_pos = nullptr, *pk_cu = nullptr, *pk_focus = nullptr;
+  // four words of host memory mapped into the device: {token count, tag, error word, tag}, written by the last
+  // kernels of clip_forward_padded's two stages; the host spins on the tags (no copy, no stream wait)
+  volatile int32_t* host_words = nullptr;
+  int32_t* host_words_dev = nullptr;
+  int32_t host_tag = 0;
   uint32_t epoch = 0;
   // LM prediction head of BertContextMLMSwitch (bert_model.py:113,165; optional weights mlm_predictions.*)
   void *w_mlm_t = nullptr, *w_mlm_dec = nullptr;  // transform dense [H,H]; decoder [vocab_pad,H] (zero rows past vocab)
@@ -241,7 +249,9 @@ int alloc_workspace(clip_engine* e) {
     rc = rc ? rc : dev_alloc(e, (void**)&e->xres_rm, Tp * H * 2);
   }
   if (e->res32 && H % 256 == 0) rc = rc ? rc : dev_alloc(e, (void**)&e->xres32, Tp * H * 4);
-  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, 4 * n_tiles * 256 * 8);   // per 64-column chunk (gemm4.hip's 64 x 64 form)
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart, n_tiles * 256 * 8);
+  rc = rc ? rc : dev_alloc(e, (void**)&e->lnpart_tag, 4 * n_tiles * 256 * 16);   // per 64-column chunk: gemm4.hip's 64 x 64 form
+  e->lnpart_tag_bytes = 4 * n_tiles * 256 * 16;
   // (one flag per 64-row tile: 4x what the ping-pong kernel needs; gemm4.hip's small-M form uses them all)
   rc = rc ? rc : dev_alloc(e, (void**)&e->lnflags, 16 * n_tiles * 4);      // per 64 x 64 tile
   e->ln_tiles = 16 * n_tiles;
@@ -252,12 +262,21 @@ int alloc_workspace(clip_engine* e) {
   rc = rc ? rc : dev_alloc(e, (void**)&e->pk_cu, ((size_t)c->max_seqs + 1) * 4);
   rc = rc ? rc : dev_alloc(e, (void**)&e->pk_focus, (size_t)c->max_seqs * 4);
   if (rc) return rc;
+  {
+    void* hp = nullptr;
+    HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+    memset(hp, 0, 64);
+    e->host_words = static_cast<volatile int32_t*>(hp);
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->host_words_dev, hp, 0));
+  }
+  if (rc) return rc;
   if (two_copies) {
     HIP_TRY(hipMemset(e->xres, 0, Tp * H * 2));
     HIP_TRY(hipMemset(e->xres_rm, 0, Tp * H * 2));
   }
   if (e->xres32) HIP_TRY(hipMemset(e->xres32, 0, Tp * H * 4));
   HIP_TRY(hipMemset(e->lnflags, 0, 16 * n_tiles * 4));
+  HIP_TRY(hipMemset(e->lnpart_tag, 0, e->lnpart_tag_bytes));   // tag 0: no launch ever carries epoch 0
   HIP_TRY(hipMemset(e->dev_err, 0, 4));
   // rows between a call's token count and the next multiple of 256 are computed (never used) by the
   // persistent GEMM: keep them finite from the start
@@ -383,13 +402,14 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
     if (e->epoch == 0xffffffffu) {
       // 2^32 launches on these flags (weeks of continuous scoring): a stale flag could equal a new epoch and let a
       // tile run ahead of its partners.  Clear the flags (stream-ordered behind every earlier launch) and start over.
-      const hipError_t er = hipMemsetAsync(e->lnflags, 0, e->ln_tiles * 4, st);
+      hipError_t er = hipMemsetAsync(e->lnflags, 0, e->ln_tiles * 4, st);
+      if (er == hipSuccess) er = hipMemsetAsync(e->lnpart_tag, 0, e->lnpart_tag_bytes, st);
       if (er != hipSuccess) return er;
       e->epoch = 0;
     }
     a.lnout = LnOutArgs{res32 ? reinterpret_cast<uint16_t*>(e->xres32) : single ? nullptr : e->xres,
                         res32 ? !first_res : (!single && !first_res), e->lnpart, e->lnflags, ++e->epoch,
-                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u, res32, e->small_m};
+                        c.layer_norm_eps, e->dev_err, e->test_drop ? 1u : 0u, res32, e->small_m, e->lnpart_tag};
     first_res = false;
     return KS::launch_gemm(a, st);
   };
@@ -657,6 +677,7 @@ int clip_destroy(clip_engine* e) {
   if (!e) return CLIP_OK;
   (void)hipSetDevice(e->device);
   for (void* p : e->allocs) (void)hipFree(p);
+  if (e->host_words) (void)hipHostFree(const_cast<int32_t*>(e->host_words));
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   delete e;
   return CLIP_OK;
@@ -826,13 +847,28 @@ int clip_forward_packed(clip_engine* e, const int32_t* ids, const int32_t* type_
   return forward_packed_impl<k_bf16>(e, ids, type_ids, pos_ids, cu, focus, n_seqs, T, max_seqlen, head_kind, logits, stream);
 }
 
+// Spin on a tag the device writes to mapped host memory behind the kernels queued so far; falls back to a stream wait
+// (which also surfaces a failed launch) when the tag does not show within ~2 s.
+static int wait_host_tag(clip_engine* e, int slot, int32_t tag, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; ++spins) {
+    if (__atomic_load_n(const_cast<const int32_t*>(e->host_words + slot + 1), __ATOMIC_ACQUIRE) == tag) return CLIP_OK;
+    if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (__atomic_load_n(const_cast<const int32_t*>(e->host_words + slot + 1), __ATOMIC_ACQUIRE) == tag) return CLIP_OK;
+      return fail(CLIP_ERR_HIP, "clip_forward_padded: the device never published its word");
+    }
+  }
+}
+
 int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t* attention_mask,
                         const int64_t* token_type_ids, const int64_t* position_ids, int64_t position_row_stride,
                         int32_t B, int32_t S, int32_t sep_id, int32_t n_ctx, int32_t head_kind, float* logits,
-                        int32_t* total_tokens, void* stream) {
+                        int32_t* total_tokens, int32_t* error_flags, void* stream) {
   if (!e || !input_ids || !logits) return fail(CLIP_ERR_ARG, "clip_forward_padded: null argument");
   if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_padded: weights not finalized");
   if (total_tokens) *total_tokens = 0;
+  if (error_flags) *error_flags = 0;
   if (B == 0) return CLIP_OK;
   if (B < 0 || S < 1 || position_row_stride < 0)
     return fail(CLIP_ERR_ARG, "clip_forward_padded: bad sizes (batch %d, width %d)", B, S);
@@ -841,12 +877,14 @@ int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t*
                 e->cfg.max_seqs);
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
-  // lengths and row offsets first: the launch geometry of everything after needs the token count on the host
-  // (the one wait of this entry point, behind two tiny kernels)
-  HIP_TRY(launch_pack_lengths(attention_mask, B, S, e->pk_cu, st));
-  int32_t T = 0;
-  HIP_TRY(hipMemcpyAsync(&T, e->pk_cu + B, 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  // lengths and row offsets first: the launch geometry of everything after needs the token count on the host — the one
+  // wait before the encoder, behind two tiny kernels: the scan writes the count to mapped host memory and the host
+  // spins on its tag (a 4-byte copy back plus a stream wait cost several times the kernels themselves)
+  const int32_t tag = ++e->host_tag;
+  HIP_TRY(launch_pack_lengths(attention_mask, B, S, e->pk_cu, e->host_words_dev, tag, st));
+  int rc = wait_host_tag(e, 0, tag, st);
+  if (rc) return rc;
+  const int32_t T = e->host_words[0];
   if (total_tokens) *total_tokens = T;
   if (T > e->cfg.max_tokens)
     return fail(CLIP_ERR_CAPACITY, "clip_forward_padded: batch of %d rows / %d tokens exceeds the engine workspace (%d / %d)",
@@ -857,8 +895,18 @@ int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t*
   // wrong [SEP] count (bert_model.py:51-55): bit 0 of the ENGINE's error word, read by the same poll as the rest
   HIP_TRY(launch_focus_index(e->pk_ids, e->pk_cu, B, sep_id, head_kind == 1 ? -1 : n_ctx, e->pk_focus, e->dev_err, st));
   const int max_seqlen = S < e->cfg.max_position ? S : e->cfg.max_position;   // a longer row: error word bit 2
-  return clip_forward_packed(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu, e->pk_focus, B, T,
-                             max_seqlen, head_kind, logits, stream);
+  rc = clip_forward_packed(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu, e->pk_focus, B, T,
+                           max_seqlen, head_kind, logits, stream);
+  if (rc || !error_flags) return rc;
+  // the caller asked for the error word: published behind the forward the same way, cleared when set (as clip_poll_errors)
+  HIP_TRY(launch_publish_word(e->dev_err, e->host_words_dev + 2, tag, st));
+  if ((rc = wait_host_tag(e, 2, tag, st))) return rc;
+  *error_flags = e->host_words[2];
+  if (*error_flags) {
+    HIP_TRY(hipMemsetAsync(e->dev_err, 0, 4, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return CLIP_OK;
 }
 
 int clip_mlm_head(clip_engine* e, const int32_t* rows, const int32_t* labels, int32_t n, float* scores_out,

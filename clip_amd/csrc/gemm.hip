@@ -10,8 +10,8 @@
 //     encoder GEMMs (M = tokens of a step).  Per K tile a wave issues 24 ds_read_b128 for 64
 //     MFMAs: half the LDS traffic per flop of the 128x128 tile.
 //   128x128 tile, 4 waves (2 x 2, 64x64 per wave), 64 KiB LDS — small M (pooler, trimmed layer).
-// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop), double-buffered;
-// the next K tile's DMA is issued before the current tile's MFMAs, one barrier per K tile.  LDS
+// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop) through a ring of LDS buffers (2 for
+// the 256-row tile, 4 for the 128-row one); DMA runs ahead of the MFMAs behind counted vmcnt, one barrier per K tile.  LDS
 // rows are 128 B; 16-B chunks are XOR-swizzled (swz128) on the SOURCE address (the image the DMA
 // writes is lane-linear) and on the ds_read_b128: conflict-free operand reads.
 // MFMA orientation: a = W fragment (rows n), b = activation fragment (cols m), so each lane ends
@@ -30,6 +30,8 @@ namespace {
 // mfma_f32_16x16x4f32 (a k-ordered fmaf chain, 1/16 of the bf16 rate).  A lane's 16-byte chunk
 // holds 4 consecutive k of its row; MFMA m of a k-step takes element m of every lane's chunk, so
 // its k set is {4 fq + m}: any order works as long as both operands use the same one.
+constexpr int gemm_stages(int bm) { return bm <= 128 ? 4 : 2; }   // LDS ring depth by tile height (<= 3 tiles in flight)
+
 template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias,
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF_BYTES = A_BYTES + W_BYTES;
   constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;  // 1-KiB DMA pieces per wave
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A | W]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST buf][A | W]
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each
   // XCD a contiguous run of tiles, n fastest, so neighbouring tiles (same A panel) hit one L2.
@@ -100,13 +102,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   const int a_off = (wm * TM * 16 + fr) * 128;
   const int w_off = A_BYTES + (wn * TN * 16 + fr) * 128;
 
+  // The 128 x 128 tile (small M: a call of a few hundred rows, step tails) keeps NST - 1 = 3 K tiles in flight: with
+  // one (the 256 x 256 tile's double buffer) every K tile of a small call waits out a full load latency.
+  constexpr int NST = gemm_stages(BM), D = NST - 1, PIECES = A_PIECES + W_PIECES;
   const int nt = K / BKE;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nt) stage(s, s);
   for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nt && GEMM_ABLATE != 2) stage(t + 1, (t + 1) & 1);
-    const char* base = smem + (t & 1) * BUF_BYTES;
+    // K tile t has landed for this wave: only the tiles issued after it (PIECES DMA instructions each) may be outstanding
+    const int rem = nt - 1 - t < D - 1 ? nt - 1 - t : D - 1;
+    if (rem == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PIECES) : "memory");
+    __builtin_amdgcn_s_barrier();   // (not __syncthreads(): its fence would drain every DMA in flight)
+    if (t + D < nt && GEMM_ABLATE != 2) stage(t + D, (t + D) % NST);
+    const char* base = smem + (t % NST) * BUF_BYTES;
     if constexpr (!F32IN) {
       // all 2 x (TN + TM) fragment reads of the tile are issued up front; the compiler's counted
       // lgkmcnt waits let the first MFMAs start while the later reads are still in flight
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
 template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = gemm_stages(BM) * (BM + BN) * 128;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN, F32IN>;
   static DeviceOnce once;  // per instantiation and device
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256) void gemm_rows16_kernel(
       R16_VMCNT(8) R16_VMCNT(9) R16_VMCNT(10) R16_VMCNT(11) R16_VMCNT(12) R16_VMCNT(13)
       default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
     }
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();   // (not __syncthreads(): its fence would drain every DMA in flight)
     if (t + R16_D < nt) stage(t + R16_D, (t + R16_D) % R16_NST);
     if (w == 0) {
       const char* base = smem + (t % R16_NST) * R16_STAGE;

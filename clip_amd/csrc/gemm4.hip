@@ -287,7 +287,8 @@ __global__ __launch_bounds__(512) void gemm4_lnout_kernel(
 // kernels form inside a wave — so a batch of 8 sentences spreads over (M / 64) * (N / 64) = 192 workgroups instead of 48,
 // each pulling 16 KiB per K tile through an 8-stage LDS-DMA ring (7 tiles in flight).  The sums of the four chunks of a
 // 256-column group, which the other kernels add across waves in LDS, are added here after the exchange, in the same
-// order: ((c0 + c1) + (c2 + c3)), then the groups in index order — the SAME BITS again.
+// order: ((c0 + c1) + (c2 + c3)), then the groups in index order — the SAME BITS again.  The exchange itself carries the
+// launch's epoch inside every 8-byte word instead of in a separate flag (LnOutArgs::part_tag: 16 bytes per row and chunk).
 // blockIdx -> (panel, chunk): workgroup b runs on XCD b % 8; an XCD takes a quarter of the panels x half of the chunks,
 // so its L2 holds (P / 4) A panels and (C / 2) weight chunks instead of a bit of everything.
 constexpr int QM = 64, QN = 64;
@@ -461,43 +462,44 @@ __global__ __launch_bounds__(256) void gemm4n_lnout_kernel(
   float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
   sm = xor16_sum4(sm); sq = xor16_sum4(sq);
   sm = xor32_sum4(sm); sq = xor32_sum4(sq);
-  // (3) published per chunk (agent-scope stores), then the workgroup's flag
-  unsigned long long* part64 = reinterpret_cast<unsigned long long*>(lo.part);
-  const size_t part_base = ((size_t)tm * chunks_n) * 256 + r256;       // + chunk * 256 + row of the panel
-  if (fq == 0) {
-    const float2 P = make_float2(sm, sq);
-    unsigned long long bits;
-    __builtin_memcpy(&bits, &P, 8);
-    __hip_atomic_store(part64 + part_base + (size_t)chunk * 256 + m * 16 + fr, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // (3) published per chunk as two 8-byte words {value, epoch}: the tag travels WITH the data, so a reader needs one
+  // round trip through memory (poll the words themselves) instead of three (data, then flag, then read) — on a call
+  // this small the exchange sits on the critical path of every launch
+  unsigned long long* part64 = lo.part_tag;
+  const size_t part_base = (((size_t)tm * chunks_n) * 256 + r256) * 2;       // + (chunk * 256 + row of the panel) * 2
+  const unsigned long long tagw = (unsigned long long)lo.epoch << 32;
   const int flag_id = panel * chunks_n + chunk;
-  if (tid == 0 && !(lo.test_drop && flag_id == 1))
-    __hip_atomic_store(lo.flags + flag_id, lo.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (4) one lane per partner chunk polls its flag, bounded and sticky
-  if (tid < chunks_n && tid != chunk) {
-    const uint32_t* f = lo.flags + panel * chunks_n + tid;
-    int spins = 0;
-    bool dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
-    while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != lo.epoch) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 20)) { atomicOr(lo.err, 2); break; }
-      if ((spins & 255) == 0) dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
-    }
+  if (fq == 0 && !(lo.test_drop && flag_id == 1)) {
+    unsigned long long* dst = part64 + part_base + ((size_t)chunk * 256 + m * 16 + fr) * 2;
+    __hip_atomic_store(dst, tagw | __float_as_uint(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, tagw | __float_as_uint(sq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
-  // (5) the row's totals: chunks of a 256-column group as (c0 + c1) + (c2 + c3), the groups in index order
+  // (4)+(5) one lane per row gathers the chunks' words (its own chunk's too), bounded and sticky; the totals: chunks of
+  // a 256-column group as (c0 + c1) + (c2 + c3), the groups in index order
   float2* stat_lds = reinterpret_cast<float2*>(smem + QNST * QSTAGE);     // [64] (mean, rstd)
   if (tid < 64) {
     float2 T = make_float2(0.f, 0.f);
+    bool dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
+    int spins = 0;
     for (int k = 0; k < tiles_n; ++k) {
       float2 p[4];
+      for (;;) {
+        unsigned long long wv[8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const unsigned long long bits = __hip_atomic_load(part64 + part_base + (size_t)(4 * k + c) * 256 + tid,
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_memcpy(&p[c], &bits, 8);
+        for (int c = 0; c < 4; ++c) {
+          const unsigned long long* src = part64 + part_base + ((size_t)(4 * k + c) * 256 + tid) * 2;
+          wv[2 * c] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wv[2 * c + 1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ok = ok && (uint32_t)(wv[c] >> 32) == lo.epoch;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = make_float2(__uint_as_float((uint32_t)wv[2 * c]), __uint_as_float((uint32_t)wv[2 * c + 1]));
+        if (ok || dead) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 20)) { atomicOr(lo.err, 2); dead = true; }
+        else if ((spins & 255) == 0) dead = (__hip_atomic_load(lo.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
       }
       const float2 P = make_float2((p[0].x + p[1].x) + (p[2].x + p[3].x), (p[0].y + p[1].y) + (p[2].y + p[3].y));
       T.x += P.x; T.y += P.y;
@@ -556,7 +558,7 @@ hipError_t KSET::launch_gemm4_lnout(const GemmArgs& g, hipStream_t st) {
   if (e0 != hipSuccess) return e0;
   if (tiles_n > 8) return hipErrorNotReady;
   const int grid_n = (g.M / QM) * (g.N / QN);
-  const bool narrow = g.lnout.small_ok >= 2 && grid_n <= n_cu && grid_n % 8 == 0;
+  const bool narrow = g.lnout.small_ok >= 2 && g.lnout.part_tag && grid_n <= n_cu && grid_n % 8 == 0;
   if (!narrow && grid > n_cu) return hipErrorNotReady;          // partners must be co-resident: one workgroup per CU
   int res_mode, out_mode;
   const void* res = g.res;

@@ -30,8 +30,10 @@ struct LnOutArgs {         // EPI_BIAS_LNOUT
                            // xres32_tiled_offset (res_tiled must be set) — the residual stream never leaves fp32
   int small_ok = 0;        // 1: `flags` holds (M / 64) * (N / 256) entries (4x the ping-pong kernel's need): calls whose whole
                            // grid of 64-row tiles is resident at once may run on gemm4.hip's kernels (same bits);
-                           // 2: `flags` holds (M / 64) * (N / 64) entries and `part` (M / 256) * (N / 64) * 256 pairs as well
-                           // (16x / 4x): the 64 x 64-tile form may run too
+                           // 2: and `part_tag` is set: the 64 x 64-tile form may run too
+  unsigned long long* part_tag = nullptr;   // [(M / 256) * (N / 64) * 256][2] words {sum | epoch << 32} {sumsq | epoch << 32}:
+                           // gemm4.hip's 64 x 64-tile form tags its partials and uses no flags.  Written by that kernel
+                           // only; no word may hold a FUTURE epoch in its upper half (zero it once, and at an epoch wrap)
 };
 
 struct GemmArgs {
@@ -140,7 +142,10 @@ struct k_f16 { CLIP_KERNEL_SET_MEMBERS };
 hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_tokens, int max_seqlen,
                              int32_t* err, hipStream_t st);
 // padded [B, S] int64 tensors -> packed rows (rowwise.hip): lengths + prefix sums into cu[0..B], then the compaction
-hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, hipStream_t st);
+// (host_out: optional mapped host words {value, tag} a spinning host reads instead of copying back)
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, int32_t* host_out, int32_t tag,
+                               hipStream_t st);
+hipError_t launch_publish_word(const int32_t* word, int32_t* host_out, int32_t tag, hipStream_t st);
 hipError_t launch_pack_tokens(const int64_t* ids, const int64_t* mask, const int64_t* tt, const int64_t* pos,
                               long pos_row_stride, int B, int S, const int32_t* cu, int32_t* out_ids,
                               int32_t* out_tt, int32_t* out_pos, hipStream_t st);

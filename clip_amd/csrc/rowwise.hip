@@ -415,7 +415,9 @@ __global__ __launch_bounds__(256) void pack_lens_kernel(const int64_t* __restric
 }
 
 // cu[0] = 0, cu[1..B] <- inclusive prefix sums of the lengths pack_lens_kernel left there; ONE workgroup.
-__global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ cu, int B) {
+// host_out (optional, host memory mapped into the device): the token count and then `tag`, for a host that spins on
+// the tag instead of paying a device-to-host copy and a stream wait.
+__global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ cu, int B, int32_t* host_out, int32_t tag) {
   __shared__ int wsum[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -447,6 +449,17 @@ __global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ c
     if (tid == 1023) carry = total;
     __syncthreads();
   }
+  if (tid == 0 && host_out) {
+    __hip_atomic_store(host_out, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_out + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// The engine's error word and then `tag` to mapped host memory, behind a forward (same purpose as above).
+__global__ void publish_word_kernel(const int32_t* __restrict__ word, int32_t* host_out, int32_t tag) {
+  __hip_atomic_store(host_out, __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_out + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One wave per row: stable compaction of the kept tokens to [cu[b], cu[b + 1]).  position ids: the caller's
@@ -678,10 +691,16 @@ hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_to
   return hipGetLastError();
 }
 
-hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, hipStream_t st) {
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, int32_t* host_out, int32_t tag,
+                               hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, S, cu);
-  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cu, B);
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cu, B, host_out, tag);
+  return hipGetLastError();
+}
+
+hipError_t launch_publish_word(const int32_t* word, int32_t* host_out, int32_t tag, hipStream_t st) {
+  hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(1), 0, st, word, host_out, tag);
   return hipGetLastError();
 }
 

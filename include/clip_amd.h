@@ -123,12 +123,15 @@ int clip_forward_packed(clip_engine* e, const int32_t* dev_ids, const int32_t* d
  * (one wait for the token count, returned in *total_tokens when not NULL), finds the focus index
  * (sep_id, n_ctx as clip_focus_index; ignored for head_kind 1) and runs clip_forward_packed.  A row
  * with a wrong [SEP] count sets bit 0 of the engine's error word, a row without any unmasked token
- * (or longer than max_position) bit 2: poll with clip_poll_errors. */
+ * (or longer than max_position) bit 2.  error_flags NULL: the call returns with the forward queued;
+ * poll with clip_poll_errors.  error_flags not NULL: the call returns when the forward has finished,
+ * with the error word (bits of clip_poll_errors; cleared when set) in *error_flags.  Both waits spin
+ * on words the device writes into mapped host memory (no copy back, no stream wait). */
 int clip_forward_padded(clip_engine* e, const int64_t* dev_input_ids, const int64_t* dev_attention_mask,
                         const int64_t* dev_token_type_ids, const int64_t* dev_position_ids,
                         int64_t position_row_stride, int32_t batch, int32_t width, int32_t sep_id,
                         int32_t n_ctx, int32_t head_kind, float* dev_logits, int32_t* total_tokens,
-                        void* stream);
+                        int32_t* error_flags, void* stream);
 
 /* Replaces the numpy epilogue of the driver (apply_bert_unlabeled.py:111-124) and the per-label
  * decision of test_load.py:37-38: probs = sigmoid(logits) (fp32); labels[i,j] = (double)p > t_j
