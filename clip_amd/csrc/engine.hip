@@ -349,7 +349,7 @@ template <class KS>
 int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_ids,
                         const int32_t* pos_ids, const int32_t* cu, const int32_t* focus,
                         int32_t n_seqs, int32_t T, int32_t max_seqlen, int32_t head_kind,
-                        float* logits, void* stream) {
+                        float* logits, void* stream, bool rows_checked = false) {
   if (!e || !ids || !pos_ids || !cu || !focus || !logits)
     return fail(CLIP_ERR_ARG, "clip_forward_packed: null argument");
   if (!e->finalized) return fail(CLIP_ERR_STATE, "clip_forward_packed: weights not finalized");
@@ -369,7 +369,8 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
   const clip_config& c = e->cfg;
   const int H = c.hidden_size, I = c.intermediate_size;
   // the row table is the caller's: a row beyond max_seqlen or a table that does not end at T sets bit 2
-  HIP_TRY(launch_check_rows(cu, n_seqs, T, max_seqlen, e->dev_err, st));
+  // (clip_forward_padded built the table itself and checked the lengths while it did)
+  if (!rows_checked) HIP_TRY(launch_check_rows(cu, n_seqs, T, max_seqlen, e->dev_err, st));
 
   const bool f32 = e->f32;
   // Residual operands.  bf16 setting: the GEMM epilogue re-derives the fp32 LayerNorm output from the
@@ -455,8 +456,13 @@ int forward_packed_impl(clip_engine* e, const int32_t* ids, const int32_t* type_
       // (rows H.. of the block copy start H / 128 block rows in: the same H * H elements)
       if (kv_pp && L.wqkv_blk) { g.W = static_cast<bf16_t*>(L.wqkv_blk) + (size_t)H * H; g.w_tiled = true; g.tile = 2; }
       HIP_TRY(KS::launch_gemm(g, st));
-      HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
-      g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
+      if (n_seqs <= 32) {   // one batch of the reference's loop: the 16-row kernel reads the focus rows by index
+        g = GemmArgs{e->x, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
+        g.a_index = focus;
+      } else {
+        HIP_TRY(launch_gather_rows(e->x, focus, e->xf_rows, n_seqs, H, st));
+        g = GemmArgs{e->xf_rows, L.wqkv, L.bqkv, nullptr, e->q_rows, n_seqs, H, H, H, H, H, 0, EPI_BIAS, false};
+      }
       HIP_TRY(KS::launch_gemm(g, st));
       break;
     }
@@ -881,7 +887,8 @@ int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t*
   // wait before the encoder, behind two tiny kernels: the scan writes the count to mapped host memory and the host
   // spins on its tag (a 4-byte copy back plus a stream wait cost several times the kernels themselves)
   const int32_t tag = ++e->host_tag;
-  HIP_TRY(launch_pack_lengths(attention_mask, B, S, e->pk_cu, e->host_words_dev, tag, st));
+  const int max_seqlen = S < e->cfg.max_position ? S : e->cfg.max_position;   // a longer row: error word bit 2
+  HIP_TRY(launch_pack_lengths(attention_mask, B, S, max_seqlen, e->pk_cu, e->dev_err, e->host_words_dev, tag, st));
   int rc = wait_host_tag(e, 0, tag, st);
   if (rc) return rc;
   const int32_t T = e->host_words[0];
@@ -891,12 +898,13 @@ int clip_forward_padded(clip_engine* e, const int64_t* input_ids, const int64_t*
                 B, T, e->cfg.max_seqs, e->cfg.max_tokens);
   if (T < 1) return fail(CLIP_ERR_ARG, "clip_forward_padded: no unmasked token in the batch");
   HIP_TRY(launch_pack_tokens(input_ids, attention_mask, token_type_ids, position_ids, (long)position_row_stride, B, S,
-                             e->pk_cu, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, st));
-  // wrong [SEP] count (bert_model.py:51-55): bit 0 of the ENGINE's error word, read by the same poll as the rest
-  HIP_TRY(launch_focus_index(e->pk_ids, e->pk_cu, B, sep_id, head_kind == 1 ? -1 : n_ctx, e->pk_focus, e->dev_err, st));
-  const int max_seqlen = S < e->cfg.max_position ? S : e->cfg.max_position;   // a longer row: error word bit 2
-  rc = clip_forward_packed(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu, e->pk_focus, B, T,
-                           max_seqlen, head_kind, logits, stream);
+                             e->pk_cu, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, sep_id,
+                             head_kind == 1 ? -1 : n_ctx, e->pk_focus, e->dev_err, st));
+  // (a wrong [SEP] count, bert_model.py:51-55, is bit 0 of the ENGINE's error word: one poll for everything)
+  rc = e->f16 ? forward_packed_impl<k_f16>(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu,
+                                           e->pk_focus, B, T, max_seqlen, head_kind, logits, stream, true)
+              : forward_packed_impl<k_bf16>(e, e->pk_ids, token_type_ids ? e->pk_tt : nullptr, e->pk_pos, e->pk_cu,
+                                            e->pk_focus, B, T, max_seqlen, head_kind, logits, stream, true);
   if (rc || !error_flags) return rc;
   // the caller asked for the error word: published behind the forward the same way, cleared when set (as clip_poll_errors)
   HIP_TRY(launch_publish_word(e->dev_err, e->host_words_dev + 2, tag, st));

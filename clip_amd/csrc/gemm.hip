@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_rows16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw, int ldo, int ldres,
     const float2* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
-    const int32_t* __restrict__ res_index, int res_tiles_n) {
+    const int32_t* __restrict__ res_index, int res_tiles_n, const int32_t* __restrict__ a_index) {
   __shared__ __attribute__((aligned(16))) char smem[R16_NST * R16_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void gemm_rows16_kernel(
   const int mb = tm * 16, nb = tn * 16;
   // this wave's DMA piece: 8 rows x 128 B of the activation (w < 2) or of the weight (w >= 2)
   const int prow = (w & 1) * 8 + (lane >> 3);
-  const bf16_t* src = (w < 2 ? A + (size_t)min(mb + prow, M - 1) * lda : W + (size_t)(nb + prow) * ldw) +
+  const int arow = min(mb + prow, M - 1);
+  const bf16_t* src = (w < 2 ? A + (size_t)(a_index ? a_index[arow] : arow) * lda : W + (size_t)(nb + prow) * ldw) +
                       swz128(prow, lane & 7) * 8;
   auto stage = [&](int kt, int buf) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(src + kt * 64), LDS_PTR(smem + buf * R16_STAGE + w * 1024), 16, 0, 0);
@@ -422,13 +423,14 @@ hipError_t launch_rows16(const GemmArgs& g, hipStream_t st) {
   hipLaunchKernelGGL((gemm_rows16_kernel<EPI, OUT_F32>), dim3(((g.M + 15) / 16) * (g.N / 16)), dim3(256), 0, st,
                      static_cast<const bf16_t*>(g.A), static_cast<const bf16_t*>(g.W), g.bias, g.res, g.out, g.M, g.N,
                      g.K, g.lda, g.ldw, g.ldo, g.ldres, reinterpret_cast<const float2*>(g.ln_stats), g.ln_gamma,
-                     g.ln_beta, g.res_index, g.res_tiles_n);
+                     g.ln_beta, g.res_index, g.res_tiles_n, g.a_index);
   return hipGetLastError();
 }
 
 template <int EPI, bool OUT_F32>
 hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
   if (g.tile == 0 && g.M <= 32 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_rows16<EPI, OUT_F32>(g, st);   // a batch's rows
+  if (g.a_index) return hipErrorInvalidValue;
   // big tile once it fills the chip about once over; the small tile otherwise
   const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
   if (g.tile == 256 || (g.tile == 0 && big_tiles >= 192 && g.N % 256 == 0))

@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* ln_gamma = nullptr;   // [N]
   const float* ln_beta = nullptr;    // [N]
   const int32_t* res_index = nullptr;  // optional: residual row of output row m is res_index[m] (one-tile kernel only)
+  const int32_t* a_index = nullptr;    // optional, M <= 32 only (gemm_rows16_kernel): row m of A is A[a_index[m]] (no gather pass)
   int res_tiles_n = 0;                 // EPI_BIAS_RES16: > 0 = res is tiled (xres_tiled_offset) with that many column tiles;
                                        // < 0 = res is FP32, tiled by xres32_tiled_offset with -res_tiles_n column tiles
   LnOutArgs lnout = {nullptr, false, nullptr, nullptr, 0, 0.f, nullptr, 0};  // EPI_BIAS_LNOUT: res = fp16 rows, ln_gamma/ln_beta = this LayerNorm's affine
@@ -143,12 +144,14 @@ hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_to
                              int32_t* err, hipStream_t st);
 // padded [B, S] int64 tensors -> packed rows (rowwise.hip): lengths + prefix sums into cu[0..B], then the compaction
 // (host_out: optional mapped host words {value, tag} a spinning host reads instead of copying back)
-hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, int32_t* host_out, int32_t tag,
-                               hipStream_t st);
+// (max_len, err: a row of < 1 or > max_len kept tokens sets bit 2 of *err, the row check of the packed forward)
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int max_len, int32_t* cu, int32_t* err,
+                               int32_t* host_out, int32_t tag, hipStream_t st);
 hipError_t launch_publish_word(const int32_t* word, int32_t* host_out, int32_t tag, hipStream_t st);
 hipError_t launch_pack_tokens(const int64_t* ids, const int64_t* mask, const int64_t* tt, const int64_t* pos,
                               long pos_row_stride, int B, int S, const int32_t* cu, int32_t* out_ids,
-                              int32_t* out_tt, int32_t* out_pos, hipStream_t st);
+                              int32_t* out_tt, int32_t* out_pos, int sep_id, int n_ctx, int32_t* focus, int32_t* err,
+                              hipStream_t st);   // focus != nullptr: launch_focus_index's result on the same pass
 // logits[0..count) = NaN when *err != 0
 hipError_t launch_poison_logits(int32_t* err, float* logits, int count, hipStream_t st);
 

@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void pack_lens_kernel(const int64_t* __restric
 // cu[0] = 0, cu[1..B] <- inclusive prefix sums of the lengths pack_lens_kernel left there; ONE workgroup.
 // host_out (optional, host memory mapped into the device): the token count and then `tag`, for a host that spins on
 // the tag instead of paying a device-to-host copy and a stream wait.
-__global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ cu, int B, int32_t* host_out, int32_t tag) {
+__global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ cu, int B, int max_len,
+                                                         int32_t* __restrict__ err, int32_t* host_out, int32_t tag) {
   __shared__ int wsum[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ c
   for (int base = 0; base < B; base += 1024) {
     const int i = base + tid;
     int x = i < B ? cu[i + 1] : 0;
+    if (i < B && (x < 1 || x > max_len)) atomicOr(err, 4);     // the row check of the packed forward (check_rows_kernel)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(x, o);
@@ -455,6 +457,54 @@ __global__ __launch_bounds__(1024) void pack_scan_kernel(int32_t* __restrict__ c
   }
 }
 
+// Batches of at most 1 024 rows (the reference's are 8): pack_lens_kernel and pack_scan_kernel in ONE workgroup — the
+// 16 waves count the rows' tokens into LDS, then the same scan.
+__global__ __launch_bounds__(1024) void pack_head_kernel(const int64_t* __restrict__ mask, int B, int S, int max_len,
+                                                         int32_t* __restrict__ cu, int32_t* __restrict__ err,
+                                                         int32_t* host_out, int32_t tag) {
+  __shared__ int lens[1024];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int b = w; b < B; b += 16) {
+    int n = S;
+    if (mask) {
+      n = 0;
+      for (int j0 = 0; j0 < S; j0 += 64) {
+        const int j = j0 + lane;
+        n += __popcll(__ballot(j < S && mask[(size_t)b * S + j] != 0));
+      }
+    }
+    if (lane == 0) lens[b] = n;
+  }
+  __syncthreads();
+  int x = tid < B ? lens[tid] : 0;
+  if (tid < B && (x < 1 || x > max_len)) atomicOr(err, 4);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    int t = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int y = __shfl_up(t, o);
+      if (lane >= o) t += y;
+    }
+    if (lane < 16) wsum[lane] = t;
+  }
+  __syncthreads();
+  const int total = (w > 0 ? wsum[w - 1] : 0) + x;
+  if (tid == 0) cu[0] = 0;
+  if (tid < B) cu[tid + 1] = total;
+  if (tid == B - 1 && host_out) {
+    __hip_atomic_store(host_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_out + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // The engine's error word and then `tag` to mapped host memory, behind a forward (same purpose as above).
 __global__ void publish_word_kernel(const int32_t* __restrict__ word, int32_t* host_out, int32_t tag) {
   __hip_atomic_store(host_out, __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
@@ -472,23 +522,42 @@ __global__ __launch_bounds__(256) void pack_tokens_kernel(const int64_t* __restr
                                                           int B, int S, const int32_t* __restrict__ cu,
                                                           int32_t* __restrict__ out_ids,
                                                           int32_t* __restrict__ out_tt,
-                                                          int32_t* __restrict__ out_pos) {
+                                                          int32_t* __restrict__ out_pos, int sep_id, int n_ctx,
+                                                          int32_t* __restrict__ focus, int32_t* __restrict__ err) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int dst0 = cu[b], end = cu[b + 1];
-  int count = 0;
+  int count = 0, seps = 0, found = -1;
   for (int j0 = 0; j0 < S; j0 += 64) {
     const int j = j0 + lane;
     const size_t at = (size_t)b * S + j;
     const bool keep = j < S && (!mask || mask[at] != 0);
+    const long long id = keep ? ids[at] : 0;
     const unsigned long long m = __ballot(keep);
     const int d = dst0 + count + __popcll(m & ((1ull << lane) - 1));
-    if (keep && d < end) {   // d < end always (same mask as pack_lens_kernel); the guard bounds a racing caller
-      out_ids[d] = (int32_t)ids[at];
+    if (keep && d < end) {   // d < end always (same mask as the length kernel); the guard bounds a racing caller
+      out_ids[d] = (int32_t)id;
       if (out_tt) out_tt[d] = tt ? (int32_t)tt[at] : 0;
       out_pos[d] = pos ? (int32_t)pos[(size_t)b * pos_row_stride + j] : j;
     }
+    // focus_index_kernel's search on the same pass (focus != nullptr): the packed index of the (n_ctx+1)-th separator
+    if (focus && n_ctx >= 0) {
+      const unsigned long long ms = __ballot(keep && id == sep_id);
+      const int c = __popcll(ms);
+      if (found < 0 && seps + c > n_ctx) {
+        int k = n_ctx - seps;
+        unsigned long long mm = ms;
+        while (k-- > 0) mm &= mm - 1;
+        const int bit = __ffsll((long long)mm) - 1;
+        found = dst0 + count + __popcll(m & ((1ull << bit) - 1));
+      }
+      seps += c;
+    }
     count += __popcll(m);
+  }
+  if (focus && lane == 0) {
+    focus[b] = found >= 0 ? found : (dst0 < end ? dst0 : (dst0 > 0 ? dst0 - 1 : 0));   // (empty row: in bounds)
+    if (n_ctx >= 0 && seps != 2 * n_ctx + 1) atomicOr(err, 1);
   }
 }
 
@@ -691,11 +760,15 @@ hipError_t launch_check_rows(const int32_t* cu_seqlens, int n_seqs, int total_to
   return hipGetLastError();
 }
 
-hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int32_t* cu, int32_t* host_out, int32_t tag,
-                               hipStream_t st) {
+hipError_t launch_pack_lengths(const int64_t* mask, int B, int S, int max_len, int32_t* cu, int32_t* err,
+                               int32_t* host_out, int32_t tag, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, S, cu);
-  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cu, B, host_out, tag);
+  if (B <= 1024) {
+    hipLaunchKernelGGL(pack_head_kernel, dim3(1), dim3(1024), 0, st, mask, B, S, max_len, cu, err, host_out, tag);
+  } else {
+    hipLaunchKernelGGL(pack_lens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, mask, B, S, cu);
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cu, B, max_len, err, host_out, tag);
+  }
   return hipGetLastError();
 }
 
@@ -706,10 +779,11 @@ hipError_t launch_publish_word(const int32_t* word, int32_t* host_out, int32_t t
 
 hipError_t launch_pack_tokens(const int64_t* ids, const int64_t* mask, const int64_t* tt, const int64_t* pos,
                               long pos_row_stride, int B, int S, const int32_t* cu, int32_t* out_ids,
-                              int32_t* out_tt, int32_t* out_pos, hipStream_t st) {
+                              int32_t* out_tt, int32_t* out_pos, int sep_id, int n_ctx, int32_t* focus, int32_t* err,
+                              hipStream_t st) {
   if (B <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, mask, tt, pos, pos_row_stride,
-                     B, S, cu, out_ids, out_tt, out_pos);
+                     B, S, cu, out_ids, out_tt, out_pos, sep_id, n_ctx, focus, err);
   return hipGetLastError();
 }
 
