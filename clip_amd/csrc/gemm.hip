@@ -435,6 +435,9 @@ hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
   const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
   if (g.tile == 256 || (g.tile == 0 && big_tiles >= 192 && g.N % 256 == 0))
     return launch_cfg<EPI, OUT_F32, 2, 4, 8, 4>(g, st);
+  // 16-bit output (QKV, FFN up of a small call): the same 128 x 128 tile on 8 waves (4 x 2, 32 x 64 per wave) — a wave's
+  // LDS-DMA stream lands at ~25 GB/s, so the tile's intake grows with the number of waves that issue it
+  if constexpr (!OUT_F32) return launch_cfg<EPI, OUT_F32, 4, 2, 2, 4>(g, st);
   return launch_cfg<EPI, OUT_F32, 2, 2, 4, 4>(g, st);
 }
 

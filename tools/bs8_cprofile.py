@@ -1,3 +1,5 @@
+"""cProfile of the host side of tools/bs8_latency.py's loop (which Python / torch calls the per-batch time goes to):
+    python tools/bs8_cprofile.py"""
 import cProfile, pstats, sys, os, io
 sys.argv = ["bs8", "1024", "8"]
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tools")
