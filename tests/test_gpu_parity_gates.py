@@ -237,3 +237,28 @@ def test_small_m_fused_gemm_same_bits(precision, monkeypatch):
             assert np.array_equal(a, b), flag
     assert np.array_equal(out["2"][0], out["2"][1]) and np.array_equal(out["2"][0], out["2"][2])
     assert np.array_equal(out["2"][0][:24], out["2"][3])
+
+
+@pytest.mark.parametrize("hidden,heads,inter", [(1024, 16, 4096), (512, 8, 2048), (256, 4, 1024)])
+def test_small_m_kernels_same_bits_other_widths(hidden, heads, inter, monkeypatch):
+    """The small-M kernels at the other hidden sizes the engine takes (BERT-large's 1024: 16 column chunks per row panel,
+    4 column tiles; 512; 256: fewer K tiles than the 64 x 64 kernel's ring holds): batches of 8, small packed steps and
+    one big step give the SAME BITS, with the kernels on (2), restricted to 64 x 256 tiles (1) and off (0)."""
+    cfg = BertConfig(vocab_size=3000, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=inter)
+    sd = procedural_state_dict(cfg, 6)
+    flat, off = synth.packed_context_rows(400, 2, cfg.vocab_size, 256, seed=32)
+    rows = scoring.PackedRows(flat, off)
+    small = [rows.flat[rows.offsets[i]:rows.offsets[i + 1]] for i in range(24)]
+    out = {}
+    for flag in ("2", "1", "0"):
+        monkeypatch.setenv("CLIP_AMD_SMALL_M", flag)
+        m = _model(cfg, sd, 2, "bf16", tokens=65536)
+        big = scoring.BulkScorer(m, keep_logits=True).score(rows).logits
+        tiny = scoring.BulkScorer(m, keep_logits=True, tokens_per_step=1024).score(rows).logits
+        m._drop_engine()
+        out[flag] = (big, tiny, _logits(cfg, sd, small, 2, "bf16", 8))
+    assert np.isfinite(out["2"][0]).all()
+    for flag in ("2", "1"):
+        for a, b in zip(out[flag], out["0"]):
+            assert np.array_equal(a, b), flag
+    assert np.array_equal(out["2"][0], out["2"][1]) and np.array_equal(out["2"][0][:24], out["2"][2])
