@@ -26,6 +26,10 @@ namespace {
 #ifndef ATTN_PAIR
 #define ATTN_PAIR 1          // 0: diagnostic builds with the 2-D grid for every launch
 #endif
+#ifndef ATTN_NBUF
+#define ATTN_NBUF 2          // K/V tile buffers of the LDS-DMA form: NBUF - 1 tiles in flight beside the one being computed
+                             // (3: 48 KB of LDS, 3 workgroups per CU instead of 4: attention 1.89 -> 2.06 ms per step, EXPERIMENTS.md E)
+#endif
 constexpr int HD = 64;       // head dim
 constexpr int KT = 64;       // keys per tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // LDS-DMA, [buffer][k | v][64 keys x 128 B]; otherwise one buffer filled through registers.  Measured per length
   // (bench.py, alternating processes, DMA against registers): L = 32 + 10 %, 64 and 128 equal, 256 - 2 %, 512 - 6.5 %.
   constexpr bool DMA = ATTN_DMA && !KV_ONCE;
-  __shared__ __attribute__((aligned(16))) char kv_lds[(DMA ? 2 : 1) * 2 * KT * 128];
+  constexpr int NBUF = DMA ? ATTN_NBUF : 1;
+  __shared__ __attribute__((aligned(16))) char kv_lds[NBUF * 2 * KT * 128];
 
   int seq, head, qt;
   if (n_pairs > 0) {
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int n_tiles = (len + KT - 1) / KT;
   if constexpr (DMA) {
     stage_tile(0, 0);
+    if (NBUF > 2 && n_tiles > 1) stage_tile(KT, 1);
     // the Q fragments are pinned here: left alone, the compiler waits for them at their first use INSIDE the loop with
     // counted waits that, not knowing of the hidden LDS-DMA loads, would drain the next tile's loads in every iteration
 #pragma unroll
@@ -193,11 +199,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     A_STAMP_T(2)
     const char* k_lds = kv_lds;
     if constexpr (DMA) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed ...
-      __syncthreads();                                   // ... every wave's have, and tile t - 1 has been read by all
+      // this wave's pieces of tile t have landed (4 DMA instructions per tile and wave; with three buffers tile t + 1 may
+      // still be in flight) ...
+      if (NBUF > 2 && t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ... every wave's have, and tile t - 1 has been read by all (a bare barrier: __syncthreads()'s fence would drain
+      // the loads in flight; a wave's LDS reads of tile t - 1 fed MFMAs it has already issued)
+      __builtin_amdgcn_s_barrier();
       A_STAMP_T(3)
-      if (t + 1 < n_tiles) stage_tile((t + 1) * KT, (t + 1) & 1);
-      k_lds = kv_lds + (t & 1) * (2 * KT * 128);
+      if (t + NBUF - 1 < n_tiles) stage_tile((t + NBUF - 1) * KT, (t + NBUF - 1) % NBUF);
+      k_lds = kv_lds + (t % NBUF) * (2 * KT * 128);
     } else {
       __syncthreads();  // previous tile's LDS reads done
       store_tile();
