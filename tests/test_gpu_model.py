@@ -165,6 +165,47 @@ def test_padded_call_with_more_rows_than_one_scan_block(golden):
     assert torch.equal(out, ref)
 
 
+def test_forward_padded_through_the_c_abi(golden):
+    """clip_forward_padded as a binder calls it: the queued form (error_flags NULL, then
+    clip_poll_errors), the token count it hands back, the capacity errors."""
+    import ctypes as C
+    from clip_amd import _lib
+    g = golden("tiny_ctx")
+    model = build_model(g)
+    lib, h = _lib.load(), model._ensure_engine()
+    ids, mask = O.pad_batch(g["rows"][:5])
+    tt = O.token_type_ids_from_seps(ids, 102, g["n_ctx"])
+    B, S = ids.shape
+    d_ids, d_mask, d_tt = ids.cuda(), mask.cuda(), tt.cuda()
+    ref = model(input_ids=d_ids, attention_mask=d_mask, token_type_ids=d_tt)[0]
+    logits = torch.full((B, model.num_labels), float("nan"), device="cuda")
+    T = C.c_int32(-1)
+    _lib.check(lib.clip_forward_padded(h, _lib.ptr(d_ids), _lib.ptr(d_mask), _lib.ptr(d_tt), None, 0, B, S, 102, g["n_ctx"], 0,
+                                       _lib.ptr(logits), C.byref(T), None, _lib.stream_ptr()))
+    _lib.poll_errors(h)
+    assert T.value == int(mask.sum()) and torch.equal(logits, ref)
+    # a wrong [SEP] count in the queued form: bit 0 at the poll, NaN logits whether or not the caller polls
+    bad = d_ids.clone()
+    bad[2][bad[2] == 102] = 7
+    _lib.check(lib.clip_forward_padded(h, _lib.ptr(bad), _lib.ptr(d_mask), _lib.ptr(d_tt), None, 0, B, S, 102, g["n_ctx"], 0,
+                                       _lib.ptr(logits), None, None, _lib.stream_ptr()))
+    flags = C.c_int32(0)
+    _lib.check(lib.clip_poll_errors(h, C.byref(flags)))
+    assert flags.value & _lib.ERR_SEP_COUNT and torch.isnan(logits).all()
+    # more rows / tokens than the engine's workspace
+    big = torch.ones((model.max_seqs + 1, 4), dtype=torch.int64, device="cuda")
+    out = torch.empty((model.max_seqs + 1, model.num_labels), device="cuda")
+    assert lib.clip_forward_padded(h, _lib.ptr(big), None, None, None, 0, model.max_seqs + 1, 4, 102, g["n_ctx"], 0,
+                                   _lib.ptr(out), None, None, _lib.stream_ptr()) == _lib.CLIP_ERR_CAPACITY
+    wide = torch.ones((model.max_seqs, 512), dtype=torch.int64, device="cuda")      # 256 x 512 tokens > max_tokens
+    assert model.max_seqs * 512 > model.max_tokens
+    rc = lib.clip_forward_padded(h, _lib.ptr(wide), None, None, None, 0, model.max_seqs, 512, 102, g["n_ctx"], 0,
+                                 _lib.ptr(out), C.byref(T), None, _lib.stream_ptr())
+    assert rc == _lib.CLIP_ERR_CAPACITY and T.value == model.max_seqs * 512
+    _lib.check(lib.clip_poll_errors(h, C.byref(flags)))       # (the length kernel may have flagged rows: clear)
+    assert torch.equal(model(input_ids=d_ids, attention_mask=d_mask, token_type_ids=d_tt)[0], ref)
+
+
 def test_no_cpu_path(golden):
     g = golden("tiny_ctx")
     model = args_to_model(2)(g["cfg"])
