@@ -92,7 +92,11 @@ def test_rccl_group_and_fused_flow_in_one_process():
     production kernel flow (fused-LayerNorm GEMMs ON — the two-rank rehearsals above share a card and must switch them
     off) in the same process.  The N >= 2 RCCL runs themselves are the driver's, on a whole node."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CLIP_AMD_FUSED_LN")}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    import socket
+    with socket.socket() as sk:                      # a free port for the one-rank rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     p = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "tests", "rccl_one_rank_child.py")], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
