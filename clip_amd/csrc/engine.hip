@@ -859,6 +859,7 @@ static int wait_host_tag(clip_engine* e, int slot, int32_t tag, hipStream_t st) 
   const auto t0 = std::chrono::steady_clock::now();
   for (long spins = 0;; ++spins) {
     if (__atomic_load_n(const_cast<const int32_t*>(e->host_words + slot + 1), __ATOMIC_ACQUIRE) == tag) return CLIP_OK;
+    __builtin_ia32_pause();
     if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
       HIP_TRY(hipStreamSynchronize(st));
       if (__atomic_load_n(const_cast<const int32_t*>(e->host_words + slot + 1), __ATOMIC_ACQUIRE) == tag) return CLIP_OK;

@@ -128,8 +128,10 @@ int clip_forward_packed(clip_engine* e, const int32_t* dev_ids, const int32_t* d
  * with the error word (bits of clip_poll_errors; cleared when set) in *error_flags.  Both waits spin
  * on words the device writes into mapped host memory (no copy back, no stream wait; after 2 s without
  * the word the call falls back to a stream wait and reports CLIP_ERR_HIP if it is still missing).
- * Because it waits on the host in its middle, this entry point cannot be captured into a HIP graph
- * (clip_forward_packed can: the caller then owns the packing and the token count). */
+ * Because it waits on the host in its middle, this entry point cannot be captured into a HIP graph.
+ * (clip_forward_packed has no host wait, but in the fused-LayerNorm flow every launch carries an epoch
+ * numbered on the host: a captured forward must not be REPLAYED in that flow either — the replay
+ * would meet its own flags.  Only clip_gemm_bf16_lnout_noalloc is built and tested for replay.) */
 int clip_forward_padded(clip_engine* e, const int64_t* dev_input_ids, const int64_t* dev_attention_mask,
                         const int64_t* dev_token_type_ids, const int64_t* dev_position_ids,
                         int64_t position_row_stride, int32_t batch, int32_t width, int32_t sep_id,
