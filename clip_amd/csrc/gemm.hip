@@ -10,8 +10,9 @@
 //     encoder GEMMs (M = tokens of a step).  Per K tile a wave issues 24 ds_read_b128 for 64
 //     MFMAs: half the LDS traffic per flop of the 128x128 tile.
 //   128x128 tile, 4 waves (2 x 2, 64x64 per wave), 64 KiB LDS — small M (pooler, trimmed layer).
-// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop) through a ring of LDS buffers (2 for
-// the 256-row tile, 4 for the 128-row one); DMA runs ahead of the MFMAs behind counted vmcnt, one barrier per K tile.  LDS
+// Operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR hop) through a ring of LDS buffers (2, or 4 for
+// 128-row tiles on a grid of at most one workgroup per CU); DMA runs ahead of the MFMAs behind counted vmcnt, one
+// barrier per K tile.  LDS
 // rows are 128 B; 16-B chunks are XOR-swizzled (swz128) on the SOURCE address (the image the DMA
 // writes is lane-linear) and on the ds_read_b128: conflict-free operand reads.
 // MFMA orientation: a = W fragment (rows n), b = activation fragment (cols m), so each lane ends
@@ -30,9 +31,9 @@ namespace {
 // mfma_f32_16x16x4f32 (a k-ordered fmaf chain, 1/16 of the bf16 rate).  A lane's 16-byte chunk
 // holds 4 consecutive k of its row; MFMA m of a k-step takes element m of every lane's chunk, so
 // its k set is {4 fq + m}: any order works as long as both operands use the same one.
-constexpr int gemm_stages(int bm) { return bm <= 128 ? 4 : 2; }   // LDS ring depth by tile height (<= 3 tiles in flight)
-
-template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
+// NST: LDS ring depth (2: double buffer, 64 KiB for the 128 x 128 tile, two workgroups per CU; 4: three K tiles in
+// flight, 128 KiB, one workgroup per CU — the launcher takes 4 when the grid has at most one workgroup per CU anyway)
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false, int NST = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
     const void* __restrict__ Av, const void* __restrict__ Wv, const float* __restrict__ bias,
     const void* __restrict__ resv, void* __restrict__ out, int M, int N, int K, int lda, int ldw,
@@ -102,9 +103,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   const int a_off = (wm * TM * 16 + fr) * 128;
   const int w_off = A_BYTES + (wn * TN * 16 + fr) * 128;
 
-  // The 128 x 128 tile (small M: a call of a few hundred rows, step tails) keeps NST - 1 = 3 K tiles in flight: with
-  // one (the 256 x 256 tile's double buffer) every K tile of a small call waits out a full load latency.
-  constexpr int NST = gemm_stages(BM), D = NST - 1, PIECES = A_PIECES + W_PIECES;
+  // NST - 1 K tiles in flight: with one (the double buffer) every K tile of a small call waits out a full load latency.
+  constexpr int D = NST - 1, PIECES = A_PIECES + W_PIECES;
   const int nt = K / BKE;
 #pragma unroll
   for (int s = 0; s < D; ++s)
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   // (now idle) staging LDS and writes whole 128-B (bf16) / 256-B (f32) row segments, 16 B per lane.
   static_assert(TN == 4, "epilogue assumes 64 output columns per wave");
   __syncthreads();  // every wave is done reading the last K tile
-  char* ep = smem + w * 16384;
+  constexpr int EP_STRIDE = OUT_F32 ? 16384 : TM * 16 * 128;   // one wave's transpose image (f32: passes of 64 rows x 256 B)
+  static_assert(NW * EP_STRIDE <= NST * BUF_BYTES, "the epilogue images must fit the staging ring");
+  char* ep = smem + w * EP_STRIDE;
   float4 bv[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -285,12 +287,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(
   }
 }
 
-template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false>
+template <int EPI, bool OUT_F32, int WAVES_M, int WAVES_N, int TM, int TN, bool F32IN = false, int NST = 2>
 hipError_t launch_cfg(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-  constexpr int LDS = gemm_stages(BM) * (BM + BN) * 128;
+  constexpr int LDS = NST * (BM + BN) * 128;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN, F32IN>;
+  auto kfn = gemm_bf16_kernel<EPI, OUT_F32, WAVES_M, WAVES_N, TM, TN, F32IN, NST>;
   static DeviceOnce once;  // per instantiation and device
   int unused = 0;
   hipError_t e0 = once.get([&](int, int*) {
@@ -437,8 +439,18 @@ hipError_t launch_one(const GemmArgs& g, hipStream_t st) {
     return launch_cfg<EPI, OUT_F32, 2, 4, 8, 4>(g, st);
   // 16-bit output (QKV, FFN up of a small call): the same 128 x 128 tile on 8 waves (4 x 2, 32 x 64 per wave) — a wave's
   // LDS-DMA stream lands at ~25 GB/s, so the tile's intake grows with the number of waves that issue it
-  if constexpr (!OUT_F32) return launch_cfg<EPI, OUT_F32, 4, 2, 2, 4>(g, st);
-  return launch_cfg<EPI, OUT_F32, 2, 2, 4, 4>(g, st);
+  // and through a 4-deep ring when the grid leaves one workgroup per CU anyway (a batch of 8: 0.895 -> 0.868 ms); bigger
+  // grids keep the double buffer, whose 64 KiB let two workgroups share a CU (batches of 32: 1.59 -> 1.50 ms)
+  static DeviceOnce cus;
+  int n_cu = 0;
+  const hipError_t e0 = cus.get([](int dev, int* val) {
+    return hipDeviceGetAttribute(val, hipDeviceAttributeMultiprocessorCount, dev);
+  }, &n_cu);
+  if (e0 != hipSuccess) return e0;
+  const bool deep = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) <= n_cu;
+  if constexpr (!OUT_F32)
+    return deep ? launch_cfg<EPI, OUT_F32, 4, 2, 2, 4, false, 4>(g, st) : launch_cfg<EPI, OUT_F32, 4, 2, 2, 4>(g, st);
+  return deep ? launch_cfg<EPI, OUT_F32, 2, 2, 4, 4, false, 4>(g, st) : launch_cfg<EPI, OUT_F32, 2, 2, 4, 4>(g, st);
 }
 
 }  // namespace
